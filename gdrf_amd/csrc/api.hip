@@ -1,0 +1,468 @@
+// libgdrf_hip: C-ABI entry points (include/gdrf_hip.h) and launch sequencing.  gfx950 only.
+#include "../../include/gdrf_hip.h"
+#include "common.h"
+#include "gemm_nt.h"
+#include "gemm_tn.h"
+#include "kernels_mm.h"
+#include "kernels_n.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gdrf;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* what, const char* detail) {
+  g_err = std::string(what) + ": " + detail;
+  return code;
+}
+#define HIPCHK(x)                                                             \
+  do {                                                                        \
+    hipError_t e_ = (x);                                                      \
+    if (e_ != hipSuccess) return fail(-(int)e_ - 1000, #x, hipGetErrorString(e_)); \
+  } while (0)
+#define LAUNCHCHK(name)                                                       \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) return fail(-(int)e_ - 1000, name, hipGetErrorString(e_)); \
+  } while (0)
+
+struct gdrf_ctx {
+  int dev, M, Mp, K, V, D, dtype, kind;
+  int64_t ncap, ldk;          // ldk = leading dimension of the (K, n) arrays
+  size_t esz;
+  int nt;                     // 128-wide tiles over Mp
+  int nsplit_cap;
+  // M x M (ld Mp)
+  void *Kuu, *Lw, *L, *LT, *Linv, *LinvT, *Dinv, *S, *ST, *Bm, *t0, *t1, *t2, *Sbar;
+  void *phi, *Cf;
+  // N side
+  void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
+  // partials
+  void *slab, *ubar_part, *phibar_part;
+  double *dpart, *dsmall;     // dsmall: [0..1] kuu sums, [2..9] scratch
+  int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
+  double* alpha_dev; double lgam_const;
+  Hyper* hyp; int* flag;
+  std::vector<void*> allocs;
+};
+
+const char* gdrf_last_error(void) { return g_err.c_str(); }
+int gdrf_version(void) { return 1; }
+
+static int64_t poff(const gdrf_ctx* c, int which) {
+  // flat parameter layout; every segment starts on a multiple of 4 elements
+  const int64_t o_uloc = 4, o_phi = round_up(o_uloc + (int64_t)c->K * c->M, 4);
+  const int64_t o_S = round_up(o_phi + (int64_t)c->K * c->V, 4);
+  const int64_t total = round_up(o_S + (int64_t)c->K * c->M * c->M, 4);
+  switch (which) { case 0: return 0; case 1: return 1; case 2: return 2; case 3: return o_uloc; case 4: return o_phi;
+                   case 5: return o_S; default: return total; }
+}
+static int64_t roff(const gdrf_ctx* c, int which) {
+  const int64_t mm = (int64_t)c->Mp * c->Mp;
+  const int64_t o_ubar = 0, o_phib = round_up((int64_t)c->K * c->Mp, 4), o_A = round_up(o_phib + (int64_t)c->K * c->V, 4);
+  const int64_t o_GT = o_A + c->K * mm, total = o_GT + mm;
+  switch (which) { case 0: return o_ubar; case 1: return o_phib; case 2: return o_A; case 3: return o_GT; default: return total; }
+}
+
+int gdrf_param_layout(const gdrf_ctx* c, int64_t out[7]) { for (int i = 0; i < 7; ++i) out[i] = poff(c, i); return 0; }
+int gdrf_red_layout(const gdrf_ctx* c, int64_t out[6]) {
+  for (int i = 0; i < 5; ++i) out[i] = roff(c, i);
+  out[5] = 8;
+  return 0;
+}
+
+static int tn_nsplit(const gdrf_ctx* c, int64_t n, int BR) {
+  const int tiles = c->K * c->nt * (c->nt + 1) / 2;
+  int ns = (1024 + tiles - 1) / tiles;
+  if (ns > 32) ns = 32;
+  const int64_t maxs = (n + 8 * BR - 1) / (8 * BR);      // at least 8 chunks per split
+  if (ns > maxs) ns = (int)maxs;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
+int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id) {
+  if (!out || n_cap < 1 || M < 1 || K < 1 || V < 1 || D < 1) return fail(-1, "gdrf_ctx_create", "bad size");
+  if (K > GDRF_KMAX) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 32 not supported");
+  if (D > GDRF_DMAX) return fail(-1, "gdrf_ctx_create", "more than 4 input dimensions not supported");
+  if (dtype != GDRF_F32 && dtype != GDRF_F64) return fail(-1, "gdrf_ctx_create", "dtype");
+  if (kernel_id != GDRF_RBF && kernel_id != GDRF_MATERN52) return fail(-1, "gdrf_ctx_create", "kernel_id");
+  HIPCHK(hipSetDevice(device));
+  gdrf_ctx* c = new gdrf_ctx();
+  c->dev = device; c->M = M; c->Mp = (int)round_up(M, GDRF_MPAD); c->K = K; c->V = V; c->D = D;
+  c->dtype = dtype; c->kind = kernel_id; c->ncap = n_cap; c->ldk = round_up(n_cap, 4);
+  c->esz = dtype == GDRF_F32 ? 4 : 8;
+  c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
+  c->lgam_const = 0; c->alpha_dev = nullptr;
+  const size_t mm = (size_t)c->Mp * c->Mp * c->esz;
+  auto A = [&](void** p, size_t bytes) -> int {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc", hipGetErrorString(e));
+    c->allocs.push_back(*p);
+    return 0;
+  };
+  int rc = 0;
+#define AL(ptr, bytes) if ((rc = A((void**)&(ptr), (bytes)))) { gdrf_ctx_destroy(c); return rc; }
+  AL(c->Kuu, mm) AL(c->Lw, mm) AL(c->L, mm) AL(c->LT, mm) AL(c->Linv, mm) AL(c->LinvT, mm)
+  AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->esz)
+  AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
+  AL(c->t0, mm) AL(c->t1, mm) AL(c->t2, mm)
+  AL(c->phi, (size_t)K * V * c->esz) AL(c->Cf, (size_t)K * M * c->esz)
+  AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
+  AL(c->q, (size_t)c->ldk * c->esz) AL(c->asum, (size_t)c->ldk * c->esz)
+  AL(c->loc, (size_t)K * c->ldk * c->esz) AL(c->tt, (size_t)K * c->ldk * c->esz) AL(c->vbar, (size_t)K * c->ldk * c->esz)
+  AL(c->locbar, (size_t)K * c->ldk * c->esz) AL(c->mu, (size_t)K * c->ldk * c->esz)
+  c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
+  AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
+  c->ubar_blocks_cap = (n_cap + 2047) / 2048;
+  AL(c->ubar_part, (size_t)c->ubar_blocks_cap * K * c->Mp * c->esz)
+  c->erows_grid_cap = 1024;
+  AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
+  const int64_t rtiles = (n_cap + GDRF_TILE - 1) / GDRF_TILE;
+  c->dpart_len = std::max<int64_t>(rtiles * c->nt * 2, 8192);
+  AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
+  AL(c->dsmall, 16 * sizeof(double))
+  AL(c->alpha_dev, (size_t)K * V * sizeof(double))
+  AL(c->hyp, sizeof(Hyper)) AL(c->flag, 16)
+#undef AL
+  HIPCHK(hipMemset(c->flag, 0, 16));
+  HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
+  std::vector<double> a((size_t)K * V, 1.0);
+  *out = c;
+  return gdrf_set_dirichlet(c, a.data());
+}
+
+void gdrf_ctx_destroy(gdrf_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+}
+
+int gdrf_set_dirichlet(gdrf_ctx* c, const double* alpha) {
+  HIPCHK(hipSetDevice(c->dev));
+  double lg = 0;
+  for (int k = 0; k < c->K; ++k) {
+    double s = 0;
+    for (int v = 0; v < c->V; ++v) {
+      const double a = alpha[(size_t)k * c->V + v];
+      if (!(a > 0)) return fail(-1, "gdrf_set_dirichlet", "b must be positive");
+      s += a; lg -= std::lgamma(a);
+    }
+    lg += std::lgamma(s);
+  }
+  c->lgam_const = lg;
+  HIPCHK(hipMemcpy(c->alpha_dev, alpha, (size_t)c->K * c->V * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) {
+  const int64_t mm = (int64_t)c->Mp * c->Mp, kn = (int64_t)c->K * c->ldk;
+  void* p = nullptr; int64_t n = 0;
+  switch (which) {
+    case 0: p = c->W; n = c->ncap * c->Mp; break;     case 1: p = c->Wbar; n = c->ncap * c->Mp; break;
+    case 2: p = c->q; n = c->ldk; break;              case 3: p = c->loc; n = kn; break;
+    case 4: p = c->tt; n = kn; break;                 case 5: p = c->vbar; n = kn; break;
+    case 6: p = c->locbar; n = kn; break;             case 7: p = c->asum; n = c->ldk; break;
+    case 8: p = c->Kuu; n = mm; break;                case 9: p = c->L; n = mm; break;
+    case 10: p = c->Linv; n = mm; break;              case 11: p = c->S; n = mm * c->K; break;
+    case 12: p = c->Bm; n = mm * c->K; break;         case 13: p = c->phi; n = (int64_t)c->K * c->V; break;
+    case 14: p = c->mu; n = kn; break;                case 15: p = c->LinvT; n = mm; break;
+    case 16: p = c->ST; n = mm * c->K; break;
+    default: return fail(-1, "gdrf_ws_ptr", "unknown buffer id");
+  }
+  *ptr = p; *nelem = n;
+  return 0;
+}
+
+int gdrf_ws_copy(gdrf_ctx* c, int which, void* dst, int64_t nelem, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  void* p; int64_t n;
+  int rc = gdrf_ws_ptr(c, which, &p, &n);
+  if (rc) return rc;
+  if (nelem > n) return fail(-1, "gdrf_ws_copy", "nelem exceeds the buffer");
+  HIPCHK(hipMemcpyAsync(dst, p, (size_t)nelem * c->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Impl {
+  using C = NTCfg<T>;
+  static T* P(void* p) { return reinterpret_cast<T*>(p); }
+  static const T* P(const void* p) { return reinterpret_cast<const T*>(p); }
+
+  static int mm_nt(gdrf_ctx* c, const T* A, int64_t abs_, const T* Bt, int64_t bbs, T* Cm, int64_t cbs, T alpha, int batch,
+                   hipStream_t s) {
+    MMProb<T> p{A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
+    dim3 grid(c->nt * c->nt, batch);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, MMProb<T>>), grid, dim3(256), C::LDS_BYTES, s, p);
+    LAUNCHCHK("mm_nt");
+    return 0;
+  }
+
+  // hyper -> Kuu(+jitter) -> Cholesky(flag) -> L, LT -> Linv, LinvT
+  static int prologue(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
+    const int Mp = c->Mp, M = c->M;
+    HIPCHK(hipMemsetAsync(c->flag, 0, 16, s));
+    hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
+    dim3 g2((Mp + 255) / 256, Mp);
+    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp, jitter, P(c->Kuu));
+    HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(T), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(chol_kernel<T>, dim3(1), dim3(1024), 0, s, P(c->Lw), M, Mp, c->flag);
+    hipLaunchKernelGGL(finalize_l_kernel<T>, g2, dim3(256), 0, s, P(c->Lw), M, Mp, P(c->L), P(c->LT));
+    hipLaunchKernelGGL(trinv_diag_kernel<T>, dim3(Mp / 32), dim3(64), 0, s, P(c->L), M, Mp, P(c->Dinv));
+    hipLaunchKernelGGL(trinv_cols_kernel<T>, dim3(Mp / 32), dim3(1024), 0, s, P(c->L), P(c->Dinv), M, Mp, P(c->Linv), P(c->LinvT));
+    LAUNCHCHK("prologue");
+    return 0;
+  }
+
+  static int knm(gdrf_ctx* c, const T* X, int64_t n, const T* Z, const T* params, T* out, int64_t ldo, hipStream_t s) {
+    hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
+    const int VE = Vec16<T>::N;
+    const int64_t total = n * ((c->M + VE - 1) / VE);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(knm_kernel<T>, dim3((unsigned)blocks), dim3(256), (size_t)c->M * c->D * sizeof(T), s, X, n, Z, c->M, c->D,
+                       c->kind, c->hyp, out, ldo);
+    LAUNCHCHK("knm");
+    return 0;
+  }
+
+  static int step_local(gdrf_ctx* c, const T* X, const int32_t* ws, const T* eps, int64_t n, const T* Z, const T* params,
+                        T* redT, double* redd, hipStream_t s) {
+    const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
+    const int64_t mm = (int64_t)Mp * Mp, ldk = c->ldk;
+    int rc;
+    const T* U = params + poff(c, 3);
+    const T* phi_unc = params + poff(c, 4);
+    const T* Sunc = params + poff(c, 5);
+    dim3 g3((Mp + 255) / 256, Mp, K);
+    hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
+    hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
+    if ((rc = mm_nt(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
+
+    const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
+    // (1) W = Knm Linv^T
+    {
+      FwdWProb<T> p{X, n, Z, M, Mp, c->D, c->kind, c->hyp, P(c->Linv), P(c->W)};
+      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdWProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), C::LDS_BYTES, s, p);
+    }
+    // q, loc
+    {
+      int64_t blocks = (n + 3) / 4; if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(rowstats_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, P(c->W), n, M, Mp, K, U, P(c->q), P(c->loc), ldk);
+    }
+    // (2) tt_kn = ||S_k^T w_n||^2
+    {
+      FwdTProb<T> p{P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
+      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
+    }
+    LAUNCHCHK("forward");
+    // per-row ELBO terms and row-local backward
+    int egrid;
+    {
+      int RB = 128;
+      size_t lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T);
+      if (lds > 150 * 1024) { RB = 64; lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T); }
+      if (lds > 150 * 1024) return fail(-1, "gdrf_step_local", "K*V too large for the row kernel's LDS budget");
+      if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)elbo_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int64_t nblk = (n + RB - 1) / RB;
+      egrid = (int)std::min<int64_t>(nblk, c->erows_grid_cap);
+      hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->q), P(c->loc), P(c->tt), eps, ldk, n,
+                         ws, P(c->phi), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+      LAUNCHCHK("elbo_rows");
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
+                         (int64_t)K * V, redT + roff(c, 1));
+    }
+    // (3) Wbar
+    {
+      BwdWbarProb<T> p{P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), C::LDS_BYTES, s, p);
+    }
+    // (4) kernel hyper-parameter partials through Knm
+    {
+      BwdKnmProb<T> p{P(c->Wbar), n, M, Mp, c->D, c->kind, P(c->LinvT), X, Z, c->hyp, c->dpart};
+      const int64_t nb = rtiles * c->nt;
+      if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdKnmProb<T>>), dim3((unsigned)nb), dim3(256), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 2, redd + 4);
+    }
+    LAUNCHCHK("backward");
+    // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
+    {
+      const int BR = TNCfg<T>::BR;
+      const int ns = tn_nsplit(c, n, BR);
+      const int64_t rps = round_up((n + ns - 1) / ns, BR);
+      TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K};
+      hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * (c->nt + 1) / 2, K, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, a);
+      dim3 gr((Mp + 255) / 256, Mp, K);
+      hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2));
+      TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, P(c->slab), 1};
+      hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * c->nt, 1, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, b);
+      dim3 gr1((Mp + 255) / 256, Mp, 1);
+      hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, s, P(c->slab), ns, 1, Mp, 0, redT + roff(c, 3));
+    }
+    // (6) ubar
+    {
+      const int64_t nb = (n + 2047) / 2048;
+      hipLaunchKernelGGL(ubar_part_kernel<T>, dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, s, P(c->W), n, Mp, K, P(c->locbar),
+                         ldk, (int64_t)2048, P(c->ubar_part));
+      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, s, P(c->ubar_part), nb, (int64_t)K * Mp,
+                         redT + roff(c, 0));
+    }
+    LAUNCHCHK("reductions");
+    return 0;
+  }
+
+  static int step_finish(gdrf_ctx* c, const T* Z, const T* params, const T* redT, const double* redd, double n_global,
+                         double ll_const, T* grads, double* out_d, hipStream_t s) {
+    const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
+    const int64_t mm = (int64_t)Mp * Mp;
+    int rc;
+    const T* ubar = redT + roff(c, 0);
+    const T* phib = redT + roff(c, 1);
+    const T* Ak = redT + roff(c, 2);
+    const T* GT = redT + roff(c, 3);
+    dim3 g2((Mp + 255) / 256, Mp);
+    // HT = GT Linv ; LbarT = -triu(HT)
+    if ((rc = mm_nt(c, GT, 0, P(c->LinvT), 0, P(c->t0), 0, T(1), 1, s))) return rc;
+    hipLaunchKernelGGL(lbar_t_kernel<T>, g2, dim3(256), 0, s, P(c->t0), Mp, P(c->t1));
+    // Q = L^T Lbar ; P = Phi(Q)
+    if ((rc = mm_nt(c, P(c->LT), 0, P(c->t1), 0, P(c->t0), 0, T(1), 1, s))) return rc;
+    hipLaunchKernelGGL(phi_tril_kernel<T>, g2, dim3(256), 0, s, P(c->t0), Mp, P(c->t2));
+    // YT = Linv^T P^T ; S' = Linv^T Y
+    if ((rc = mm_nt(c, P(c->LinvT), 0, P(c->t2), 0, P(c->t0), 0, T(1), 1, s))) return rc;
+    if ((rc = mm_nt(c, P(c->LinvT), 0, P(c->t0), 0, P(c->t1), 0, T(1), 1, s))) return rc;
+    hipLaunchKernelGGL(kuu_bar_reduce_kernel<T>, dim3(M), dim3(256), 0, s, P(c->t1), Z, M, Mp, c->D, c->kind, c->hyp, c->dpart);
+    hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)M, 2, c->dsmall);
+    // Sbar_k = 2 A_k S_k
+    if ((rc = mm_nt(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, s))) return rc;
+    dim3 g3((M + 255) / 256, M, K);
+    hipLaunchKernelGGL(grad_s_kernel<T>, g3, dim3(256), 0, s, P(c->Sbar), P(c->S), M, Mp, -1.0 / n_global, grads + poff(c, 5));
+    hipLaunchKernelGGL(grad_small_kernel<T>, dim3(1), dim3(256), 0, s, M, Mp, K, V, c->hyp, redd, c->dsmall, ubar, phib, P(c->phi),
+                       c->alpha_dev, c->lgam_const, ll_const, n_global, grads, grads + poff(c, 3), grads + poff(c, 4), c->flag, out_d);
+    LAUNCHCHK("step_finish");
+    return 0;
+  }
+
+  static int predict(gdrf_ctx* c, const T* X, int64_t n, const T* Z, const T* params, const int32_t* ws, int mode,
+                     T* out, double* out_d, hipStream_t s) {
+    const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
+    const T* U = params + poff(c, 3);
+    if (mode >= 2) hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, params + poff(c, 4), K, V, P(c->phi));
+    hipLaunchKernelGGL(predict_coeff_kernel<T>, dim3((M + 127) / 128, K), dim3(128), 0, s, P(c->Linv), U, M, Mp, K, P(c->Cf));
+    size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(T);
+    int in_lds = 1;
+    if (lds > 64 * 1024) { in_lds = 0; lds -= (size_t)K * M * sizeof(T); }
+    if (lds > 48 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)predict_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = (n + 127) / 128; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    const int64_t ldo = mode == 0 ? n : (mode == 1 ? K : V);
+    hipLaunchKernelGGL(predict_rows_kernel<T>, dim3((unsigned)blocks), dim3(128), lds, s, X, n, Z, M, c->D, c->kind, c->hyp, P(c->Cf), K,
+                       V, P(c->phi), ws, mode, out, ldo, c->dpart, in_lds);
+    if (mode == 3) hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, blocks, 2, out_d);
+    LAUNCHCHK("predict");
+    return 0;
+  }
+};
+
+#define DISPATCH(c, call_f32, call_f64) ((c)->dtype == GDRF_F32 ? (call_f32) : (call_f64))
+
+int gdrf_knm(gdrf_ctx* c, const void* X, int64_t n, const void* Z, const void* params, void* out, int64_t ldo, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH(c, Impl<float>::knm(c, (const float*)X, n, (const float*)Z, (const float*)params, (float*)out, ldo, s),
+                  Impl<double>::knm(c, (const double*)X, n, (const double*)Z, (const double*)params, (double*)out, ldo, s));
+}
+
+int gdrf_fill_eps(gdrf_ctx* c, uint64_t seed, uint32_t step, int64_t n_offset, int64_t n, void* eps, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((n + 255) / 256), c->K);
+  if (c->dtype == GDRF_F32) hipLaunchKernelGGL(fill_eps_kernel<float>, grid, dim3(256), 0, s, seed, step, n_offset, n, c->K, (float*)eps, n);
+  else hipLaunchKernelGGL(fill_eps_kernel<double>, grid, dim3(256), 0, s, seed, step, n_offset, n, c->K, (double*)eps, n);
+  LAUNCHCHK("fill_eps");
+  return 0;
+}
+
+int gdrf_ll_const(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_host, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ll_const_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, n, c->V, c->dpart);
+  hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, blocks, 1, c->dsmall + 8);
+  LAUNCHCHK("ll_const");
+  HIPCHK(hipMemcpyAsync(out_host, c->dsmall + 8, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gdrf_factorize(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH(c, Impl<float>::prologue(c, (const float*)Z, (const float*)params, jitter, s),
+                  Impl<double>::prologue(c, (const double*)Z, (const double*)params, jitter, s));
+}
+
+int gdrf_step_local(gdrf_ctx* c, const void* X, const int32_t* ws, const void* eps, int64_t n, const void* Z, const void* params,
+                    void* redT, double* redd, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (n < 1 || n > c->ncap) return fail(-1, "gdrf_step_local", "n_local outside [1, n_cap]");
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH(c,
+      Impl<float>::step_local(c, (const float*)X, ws, (const float*)eps, n, (const float*)Z, (const float*)params, (float*)redT, redd, s),
+      Impl<double>::step_local(c, (const double*)X, ws, (const double*)eps, n, (const double*)Z, (const double*)params, (double*)redT, redd, s));
+}
+
+int gdrf_step_finish(gdrf_ctx* c, const void* Z, const void* params, const void* redT, const double* redd, double n_global,
+                     double ll_const, void* grads, double* out_d, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH(c,
+      Impl<float>::step_finish(c, (const float*)Z, (const float*)params, (const float*)redT, redd, n_global, ll_const, (float*)grads, out_d, s),
+      Impl<double>::step_finish(c, (const double*)Z, (const double*)params, (const double*)redT, redd, n_global, ll_const, (double*)grads, out_d, s));
+}
+
+int gdrf_adam(gdrf_ctx* c, int mode, void* params, const void* grads, void* m, void* v, int64_t t, double lr, double b1, double b2,
+              double eps, double wd, double clip, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = poff(c, 6);
+  const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (c->dtype == GDRF_F32)
+    hipLaunchKernelGGL(adam_kernel<float>, grid, dim3(256), 0, s, n, (float*)params, (const float*)grads, (float*)m, (float*)v, mode, lr,
+                       b1, b2, eps, wd, clip, bc1, bc2, (const int*)c->flag);
+  else
+    hipLaunchKernelGGL(adam_kernel<double>, grid, dim3(256), 0, s, n, (double*)params, (const double*)grads, (double*)m, (double*)v, mode,
+                       lr, b1, b2, eps, wd, clip, bc1, bc2, (const int*)c->flag);
+  LAUNCHCHK("adam");
+  return 0;
+}
+
+int gdrf_predict(gdrf_ctx* c, const void* X, int64_t n, const void* Z, const void* params, const int32_t* ws, int mode,
+                 void* out, double* out_d, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (mode < 0 || mode > 3) return fail(-1, "gdrf_predict", "mode");
+  if (mode == 3 && !ws) return fail(-1, "gdrf_predict", "perplexity needs ws");
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH(c,
+      Impl<float>::predict(c, (const float*)X, n, (const float*)Z, (const float*)params, ws, mode, (float*)out, out_d, s),
+      Impl<double>::predict(c, (const double*)X, n, (const double*)Z, (const double*)params, ws, mode, (double*)out, out_d, s));
+}
+
+int gdrf_chol_failed(gdrf_ctx* c, int* failed, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(failed, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}

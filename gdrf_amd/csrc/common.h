@@ -1,0 +1,97 @@
+// Common device/host helpers for libgdrf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GDRF_WAVE 64
+#define GDRF_TILE 128          // output tile edge of both GEMM cores
+#define GDRF_KBYTES 128        // bytes of reduction index staged per row per chunk (NT core)
+#define GDRF_MPAD 32           // M is padded to a multiple of this in every workspace matrix
+
+namespace gdrf {
+
+template <typename T> struct Vec16;                 // 16-byte vector of T
+template <> struct Vec16<float>  { using type = float  __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+
+// ---- MFMA 16x16x4 wrappers: same A/B lane maps for f32 and f64, different C/D row map
+// (cdna_hip_programming.md §3: f32 row = 4*(lane>>4)+reg ; f64 row = (lane>>4)+4*reg).
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  using acc_t = float __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return ((lane >> 4) << 2) + r; }
+};
+template <> struct Mfma<double> {
+  using acc_t = double __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + (r << 2); }
+};
+
+// ---- wave / block reductions -------------------------------------------------
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 16 lanes that share (lane>>4)
+template <typename T> __device__ __forceinline__ T group16_sum(T v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// block sum for blockDim.x <= 1024 ; result valid in thread 0 ; scratch >= 16 doubles
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) for (int i = 0; i < nw; ++i) r += scratch[i];
+  return r;
+}
+
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float  t_exp<float>(float x)   { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_log(T x);
+template <> __device__ __forceinline__ float  t_log<float>(float x)   { return logf(x); }
+template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ float  t_sqrt<float>(float x)   { return sqrtf(x); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T t_eps();
+template <> __device__ __forceinline__ float  t_eps<float>()  { return 1.1920928955078125e-07f; }
+template <> __device__ __forceinline__ double t_eps<double>() { return 2.220446049250313e-16; }
+
+// ---- covariance functions (pyro.contrib.gp.kernels.isotropic semantics, direct (x-z)^2 form)
+// kind 0 = RBF, 1 = Matern52.  r2 is the squared distance scaled by 1/lengthscale^2.
+struct KParams { double inv_ls2; double var; };     // device-side hyper-parameters (double, cast per use)
+
+template <typename T> __device__ __forceinline__ T cov_from_r2(int kind, T r2, T var) {
+  if (kind == 0) return var * t_exp<T>(T(-0.5) * r2);
+  const T r = t_sqrt<T>(r2 + T(1e-12));
+  const T a = T(2.23606797749978969641) * r;
+  return var * (T(1) + a + (T(5) / T(3)) * r * r) * t_exp<T>(-a);
+}
+// d k / d log(lengthscale)
+template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T r2, T var) {
+  if (kind == 0) return k * r2;
+  const T r = t_sqrt<T>(r2 + T(1e-12));
+  const T a = T(2.23606797749978969641) * r;
+  return var * t_exp<T>(-a) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
+}
+template <typename T> __device__ __forceinline__ T sqdist(const T* __restrict__ x, const T* __restrict__ z, int D) {
+  T s = 0;
+  for (int d = 0; d < D; ++d) { const T t = x[d] - z[d]; s += t * t; }
+  return s;
+}
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace gdrf

@@ -1,0 +1,727 @@
+// Observation-sized kernels of one SVI step (everything that is a sum over rows n).
+//
+// Reference behaviour restated (paths under /root/reference; arithmetic in SURVEY.md A.3/A.4, App. C):
+//   pyro.contrib.gp.util.conditional as called at gdrf/models/sparse_gdrf.py:334-344,384-394
+//   guide/model sample sites                      gdrf/models/sparse_gdrf.py:354-372,396-409
+//   softmax link + topic_probs @ phi              gdrf/models/abstract_gdrf.py:21-22, sparse_gdrf.py:361-362
+#pragma once
+#include "common.h"
+#include "gemm_nt.h"
+#include "kernels_mm.h"
+
+#define GDRF_DMAX 4
+
+namespace gdrf {
+
+template <typename T> __device__ __forceinline__ typename Vec16<T>::type vzero() {
+  typename Vec16<T>::type z;
+#pragma unroll
+  for (int e = 0; e < Vec16<T>::N; ++e) z[e] = 0;
+  return z;
+}
+
+// =====================================================================================
+// k_nm: the standalone pairwise covariance block K_nm (N x M, row-major).  HBM-write bound:
+// algorithmic bytes = N*M*s + N*D*s + M*D*s.  One 16-byte store per lane, rows contiguous.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64_t N, const T* __restrict__ Z, int M, int D,
+                                                  int kind, const Hyper* __restrict__ h, T* __restrict__ out, int64_t ldo) {
+  using V = typename Vec16<T>::type;
+  constexpr int VE = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Zs = reinterpret_cast<T*>(smem);                 // [M][D]
+  for (int e = threadIdx.x; e < M * D; e += blockDim.x) Zs[e] = Z[e];
+  __syncthreads();
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  const int vpr = (M + VE - 1) / VE;                   // vectors per row
+  const int64_t total = N * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = v / vpr;
+    const int i0 = (int)(v - n * vpr) * VE;
+    T x[GDRF_DMAX];
+#pragma unroll
+    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[n * D + d] : T(0);
+    V o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int i = i0 + e;
+      T r2 = 0;
+      if (i < M) {
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Zs[i * D + d]; r2 += t * t; }
+      }
+      o[e] = (i < M) ? cov_from_r2<T>(kind, r2 * ils2, var) : T(0);
+    }
+    if ((ldo % VE) == 0 && i0 + VE <= ldo) __builtin_nontemporal_store(o, reinterpret_cast<V*>(out + n * ldo + i0));
+    else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) out[n * ldo + i0 + e] = o[e];
+  }
+}
+
+// =====================================================================================
+// NT-core problems
+// =====================================================================================
+// (1) W = K_nm Linv^T : A generated on the fly, Bt = Linv, triangular k range, store W
+template <typename T> struct FwdWProb {
+  using V = typename Vec16<T>::type;
+  const T* X; int64_t nrows; const T* Z; int M, Mp, D, kind; const Hyper* h;
+  const T* Linv; T* W;
+  struct ACtx { T x[NTCfg<T>::VPT][GDRF_DMAX]; bool ok[NTCfg<T>::VPT]; T var, ils2; };
+  struct ECtx {};
+  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const {
+    kb = 0; ke = n0 + GDRF_TILE; if (ke > Mp) ke = Mp;
+  }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+    c.var = (T)h->var; c.ils2 = (T)h->inv_ls2;
+#pragma unroll
+    for (int i = 0; i < NTCfg<T>::VPT; ++i) {
+      const int64_t r = m0 + nt_stage_row<T>(i);
+      c.ok[i] = r < nrows;
+#pragma unroll
+      for (int d = 0; d < GDRF_DMAX; ++d) c.x[i][d] = (c.ok[i] && d < D) ? X[r * D + d] : T(0);
+    }
+  }
+  __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+    V o;
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) {
+      const int idx = k + e;
+      T val = 0;
+      if (c.ok[i] && idx < M) {
+        T r2 = 0;
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = c.x[i][d] - Z[(int64_t)idx * D + d]; r2 += t * t; }
+        val = cov_from_r2<T>(kind, r2 * c.ils2, c.var);
+      }
+      o[e] = val;
+    }
+    return o;
+  }
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int) const {
+    const int c = n0 + nt_stage_row<T>(i);
+    return (c < Mp) ? *reinterpret_cast<const V*>(Linv + (int64_t)c * Mp + k) : vzero<T>();
+  }
+  template <class Acc>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
+        if (m >= nrows) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int n = n0 + nt_acc_col(wc, b, lane);
+          if (n < Mp) W[m * Mp + n] = acc[a][b][r];
+        }
+      }
+  }
+  __device__ __forceinline__ void finish(int64_t, int, ECtx&, char*, int, int, int) const {}
+};
+
+// (2) T_k = W S_k (never stored) -> tt[k][n] = sum_j T_k[n][j]^2 ; one workgroup walks all column tiles
+template <typename T> struct FwdTProb {
+  using V = typename Vec16<T>::type;
+  const T* W; int64_t nrows; int Mp;
+  const T* ST;                     // [K][Mp][Mp], ST[k][j][i] = S_k[i][j]
+  T* tt; int64_t ldt;              // [K][ldt]
+  struct ACtx { const T* p[NTCfg<T>::VPT]; };
+  struct ECtx { T rs[4][4]; };
+  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ bool loop_cols() const { return true; }
+  __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const { kb = n0; ke = Mp; }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+#pragma unroll
+    for (int i = 0; i < NTCfg<T>::VPT; ++i) {
+      const int64_t r = m0 + nt_stage_row<T>(i);
+      c.p[i] = (r < nrows) ? W + r * Mp : nullptr;
+    }
+  }
+  __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e.rs[a][r] = 0;
+  }
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+    return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
+  }
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int bz) const {
+    const int c = n0 + nt_stage_row<T>(i);
+    return (c < Mp) ? *reinterpret_cast<const V*>(ST + ((int64_t)bz * Mp + c) * Mp + k) : vzero<T>();
+  }
+  template <class Acc>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t, int, int, ECtx& e, int, int, int) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e.rs[a][r] += acc[a][b][r] * acc[a][b][r];
+  }
+  __device__ __forceinline__ void finish(int64_t m0, int bz, ECtx& e, char* smem, int wr, int wc, int lane) const {
+    T* rsum = reinterpret_cast<T*>(smem);      // [128]
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e.rs[a][r] = group16_sum(e.rs[a][r]);
+    if (wc == 0 && (lane & 15) == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsum[nt_acc_row<T>(wr, a, lane, r)] = e.rs[a][r];
+    }
+    __syncthreads();
+    if (wc == 1 && (lane & 15) == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsum[nt_acc_row<T>(wr, a, lane, r)] += e.rs[a][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < GDRF_TILE) {
+      const int64_t m = m0 + threadIdx.x;
+      if (m < nrows) tt[(int64_t)bz * ldt + m] = rsum[threadIdx.x];
+    }
+  }
+};
+
+// (3) Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W ; reduction index = (k, i)
+template <typename T> struct BwdWbarProb {
+  using V = typename Vec16<T>::type;
+  const T* W; int64_t nrows; int M, Mp, K;
+  const T* Bm;                     // [K][Mp][Mp] symmetric B_k = S_k S_k^T
+  const T* vbar; const T* locbar; int64_t ldk;   // [K][ldk]
+  const T* asum;                   // [nrows] a_n * sum_k vbar_kn
+  const T* U;                      // [K][M] u_loc (unpadded)
+  T* Wbar;
+  struct ACtx { const T* p[NTCfg<T>::VPT]; int64_t r[NTCfg<T>::VPT]; };
+  struct ECtx {};
+  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = K * Mp; }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+#pragma unroll
+    for (int i = 0; i < NTCfg<T>::VPT; ++i) {
+      const int64_t r = m0 + nt_stage_row<T>(i);
+      c.r[i] = r;
+      c.p[i] = (r < nrows) ? W + r * Mp : nullptr;
+    }
+  }
+  __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+    if (!c.p[i]) return vzero<T>();
+    const int kk = k / Mp, ii = k - kk * Mp;
+    V v = *reinterpret_cast<const V*>(c.p[i] + ii);
+    const T s = T(2) * vbar[(int64_t)kk * ldk + c.r[i]];
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) v[e] *= s;
+    return v;
+  }
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int) const {
+    const int c = n0 + nt_stage_row<T>(i);
+    if (c >= Mp) return vzero<T>();
+    const int kk = k / Mp, ii = k - kk * Mp;
+    return *reinterpret_cast<const V*>(Bm + ((int64_t)kk * Mp + c) * Mp + ii);
+  }
+  template <class Acc>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
+        if (m >= nrows) continue;
+        const T as2 = T(2) * asum[m];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int n = n0 + nt_acc_col(wc, b, lane);
+          if (n >= Mp) continue;
+          T v = acc[a][b][r] - as2 * W[m * Mp + n];
+          if (n < M) for (int k = 0; k < K; ++k) v += locbar[(int64_t)k * ldk + m] * U[(int64_t)k * M + n];
+          Wbar[m * Mp + n] = v;
+        }
+      }
+  }
+  __device__ __forceinline__ void finish(int64_t, int, ECtx&, char*, int, int, int) const {}
+};
+
+// (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
+template <typename T> struct BwdKnmProb {
+  using V = typename Vec16<T>::type;
+  const T* Wbar; int64_t nrows; int M, Mp, D, kind;
+  const T* LinvT;                  // [Mp][Mp], LinvT[i][j] = Linv[j][i]
+  const T* X; const T* Z; const Hyper* h;
+  double* part;                    // [gridDim.x][2]
+  struct ACtx { const T* p[NTCfg<T>::VPT]; };
+  struct ECtx { T s1, s2; };
+  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const { kb = n0; ke = Mp; }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+#pragma unroll
+    for (int i = 0; i < NTCfg<T>::VPT; ++i) {
+      const int64_t r = m0 + nt_stage_row<T>(i);
+      c.p[i] = (r < nrows) ? Wbar + r * Mp : nullptr;
+    }
+  }
+  __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const { e.s1 = 0; e.s2 = 0; }
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+    return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
+  }
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int) const {
+    const int c = n0 + nt_stage_row<T>(i);
+    return (c < Mp) ? *reinterpret_cast<const V*>(LinvT + (int64_t)c * Mp + k) : vzero<T>();
+  }
+  template <class Acc>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
+    const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+    T z[4][GDRF_DMAX];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = n0 + nt_acc_col(wc, b, lane);
+#pragma unroll
+      for (int d = 0; d < GDRF_DMAX; ++d) z[b][d] = (n < M && d < D) ? Z[(int64_t)n * D + d] : T(0);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
+        if (m >= nrows) continue;
+        T x[GDRF_DMAX];
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[m * D + d] : T(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int n = n0 + nt_acc_col(wc, b, lane);
+          if (n >= M) continue;
+          T r2 = 0;
+#pragma unroll
+          for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - z[b][d]; r2 += t * t; }
+          r2 *= ils2;
+          const T kv = cov_from_r2<T>(kind, r2, var);
+          e.s1 += acc[a][b][r] * kv;
+          e.s2 += acc[a][b][r] * dcov_dlogls<T>(kind, kv, r2, var);
+        }
+      }
+  }
+  __device__ __forceinline__ void finish(int64_t, int, ECtx& e, char* smem, int, int, int) const {
+    double* scratch = reinterpret_cast<double*>(smem);
+    __syncthreads();
+    const double a = block_sum((double)e.s1, scratch);
+    const double b = block_sum((double)e.s2, scratch);
+    if (threadIdx.x == 0) { part[2 * (int64_t)blockIdx.x] = a; part[2 * (int64_t)blockIdx.x + 1] = b; }
+  }
+};
+
+// =====================================================================================
+// rowstats: q_n = ||w_n||^2, loc_kn = u_k . w_n   (one wave per row)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ W, int64_t nrows, int M, int Mp, int K,
+                                                       const T* __restrict__ U, T* __restrict__ q, T* __restrict__ loc, int64_t ldk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t n = wave; n < nrows; n += nwaves) {
+    const T* w = W + n * Mp;
+    T s = 0;
+    for (int i = lane; i < M; i += 64) { const T t = w[i]; s += t * t; }
+    s = wave_sum(s);
+    if (lane == 0) q[n] = s;
+    for (int k = 0; k < K; ++k) {
+      T d = 0;
+      for (int i = lane; i < M; i += 64) d += w[i] * U[(int64_t)k * M + i];
+      d = wave_sum(d);
+      if (lane == 0) loc[(int64_t)k * ldk + n] = d;
+    }
+  }
+}
+
+// =====================================================================================
+// elbo_rows: per observation: variance, reparameterised draw, softmax link, Multinomial
+// log-likelihood, both Normal site terms, and the row-local part of the backward.
+// One thread per row, K <= GDRF_KMAX kept in registers.
+// =====================================================================================
+#define GDRF_KMAX 32
+
+template <typename T>
+__global__ __launch_bounds__(128) void elbo_rows_kernel(
+    int64_t nrows, int K, int V, const Hyper* __restrict__ h,
+    const T* __restrict__ q, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps, int64_t ldk, int64_t lde,
+    const int32_t* __restrict__ ws, const T* __restrict__ phi,
+    T* __restrict__ vbar, T* __restrict__ locbar, T* __restrict__ asum, T* __restrict__ mu_out,
+    double* __restrict__ dpart /*[grid][4]*/, T* __restrict__ phibar_part /*[grid][K*V]*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int RB = blockDim.x;
+  double* scratch = reinterpret_cast<double*>(smem);    // [16]
+  T* phiS = reinterpret_cast<T*>(smem + 128);           // [K*V]
+  T* accS = phiS + K * V;                               // [K*V] phibar accumulator (owner-thread only)
+  T* thS = accS + K * V;                                // [RB][K+1]
+  T* pbS = thS + RB * (K + 1);                          // [RB][V+1]
+  for (int e = threadIdx.x; e < K * V; e += RB) { phiS[e] = phi[e]; accS[e] = 0; }
+  __syncthreads();
+  const T var = (T)h->var, eta = (T)h->noise;
+  const T feps = t_eps<T>();
+  double s_site = 0, s_llw = 0, s_noise = 0, s_vd = 0;
+  const int64_t nblk = (nrows + RB - 1) / RB;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t n = blk * RB + threadIdx.x;
+    const bool ok = n < nrows;
+    T* th = thS + threadIdx.x * (K + 1);
+    T* pb = pbS + threadIdx.x * (V + 1);
+    T v[GDRF_KMAX], mu[GDRF_KMAX], ep[GDRF_KMAX];
+    T a = 0, vd = 0;
+    if (ok) {
+      const T qn = q[n];
+      a = (var - qn > T(0)) ? T(1) : T(0);
+      const T v0 = a * (var - qn);
+      T mx = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) {
+        ep[k] = eps[(int64_t)k * lde + n];
+        v[k] = v0 + tt[(int64_t)k * ldk + n];
+        mu[k] = loc[(int64_t)k * ldk + n] + v[k] * ep[k];
+        mx = fmax(mx, mu[k]);
+      }
+      T se = 0;
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) { const T e = t_exp<T>(mu[k] - mx); th[k] = e; se += e; }
+      const T ise = T(1) / se;
+      for (int k = 0; k < K; ++k) th[k] *= ise;
+      // pass 1: p_v = sum_k theta_k phi_kv
+      T ps = 0;
+      for (int vv = 0; vv < V; ++vv) {
+        T p = 0;
+        for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
+        pb[vv] = p; ps += p;
+      }
+      // pass 2: log-likelihood and pbar = w * mask / p
+      const T ips = T(1) / ps;
+      T llw = 0;
+      const int32_t* wrow = ws + n * V;
+      for (int vv = 0; vv < V; ++vv) {
+        const T p = pb[vv];
+        const T ph = p * ips;
+        const T wv = (T)wrow[vv];
+        const bool inr = (ph > feps) && (ph < T(1) - feps);
+        const T phc = fmin(fmax(ph, feps), T(1) - feps);
+        llw += wv * t_log<T>(phc);
+        pb[vv] = inr ? wv / p : T(0);
+      }
+      s_llw += (double)llw;
+      // thetabar_k = sum_v phi_kv pbar_v ; softmax Jacobian
+      T tb[GDRF_KMAX];
+      T dot = 0;
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) {
+        T s = 0;
+        for (int vv = 0; vv < V; ++vv) s += phiS[k * V + vv] * pb[vv];
+        tb[k] = s; dot += th[k] * s;
+      }
+      T site = 0, ng = 0, vsum = 0;
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) {
+        const T mub = th[k] * (tb[k] - dot);
+        const T s = v[k] + eta, r = v[k] / s, e2 = ep[k] * ep[k];
+        site += -t_log<T>(s) + t_log<T>(v[k]) - T(0.5) * e2 * r * r + T(0.5) * e2;
+        const T dcdv = -T(1) / s + T(1) / v[k] - e2 * r * eta / (s * s);
+        ng += -T(1) / s + e2 * r * r / s;
+        const T vb = mub * ep[k] + dcdv;
+        vbar[(int64_t)k * ldk + n] = vb;
+        locbar[(int64_t)k * ldk + n] = mub;
+        if (mu_out) mu_out[(int64_t)k * ldk + n] = mu[k];
+        vsum += vb;
+      }
+      vd = a * vsum;
+      asum[n] = vd;
+      s_site += (double)site; s_noise += (double)ng; s_vd += (double)vd;
+    } else {
+      for (int k = 0; k < K; ++k) th[k] = 0;
+      for (int vv = 0; vv < V; ++vv) pb[vv] = 0;
+    }
+    __syncthreads();
+    // phibar_kv += sum_rows theta_k pbar_v : each (k,v) pair has one owner thread
+    for (int e = threadIdx.x; e < K * V; e += RB) {
+      const int k = e / V, vv = e - k * V;
+      T s = 0;
+      for (int r = 0; r < RB; ++r) s += thS[r * (K + 1) + k] * pbS[r * (V + 1) + vv];
+      accS[e] += s;
+    }
+    __syncthreads();
+  }
+  const double b0 = block_sum(s_site, scratch), b1 = block_sum(s_llw, scratch);
+  const double b2 = block_sum(s_noise, scratch), b3 = block_sum(s_vd, scratch);
+  if (threadIdx.x == 0) {
+    dpart[4 * (int64_t)blockIdx.x + 0] = b0; dpart[4 * (int64_t)blockIdx.x + 1] = b1;
+    dpart[4 * (int64_t)blockIdx.x + 2] = b2; dpart[4 * (int64_t)blockIdx.x + 3] = b3;
+  }
+  for (int e = threadIdx.x; e < K * V; e += RB) phibar_part[(int64_t)blockIdx.x * K * V + e] = accS[e];
+}
+
+// =====================================================================================
+// ubar partials: ubar[k][i] = sum_n locbar[k][n] W[n][i]; thread owns a column, 16 topics at a time
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void ubar_part_kernel(const T* __restrict__ W, int64_t nrows, int Mp, int K,
+                                                        const T* __restrict__ locbar, int64_t ldk, int64_t rows_per_blk,
+                                                        T* __restrict__ part /*[gridDim.x][K][Mp]*/) {
+  __shared__ T lb[16][256];
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  int64_t r1 = r0 + rows_per_blk; if (r1 > nrows) r1 = nrows;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    T acc[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc[kk] = 0;
+    for (int64_t rs = r0; rs < r1; rs += 256) {
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int64_t n = rs + threadIdx.x;
+        lb[kk][threadIdx.x] = (k0 + kk < K && n < r1) ? locbar[(int64_t)(k0 + kk) * ldk + n] : T(0);
+      }
+      __syncthreads();
+      const int cnt = (int)((r1 - rs < 256) ? (r1 - rs) : 256);
+      if (col < Mp) {
+        for (int r = 0; r < cnt; ++r) {
+          const T w = W[(rs + r) * Mp + col];
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) acc[kk] += lb[kk][r] * w;
+        }
+      }
+    }
+    if (col < Mp) {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        if (k0 + kk < K) part[((int64_t)blockIdx.x * K + k0 + kk) * Mp + col] = acc[kk];
+    }
+  }
+}
+
+// =====================================================================================
+// reductions of per-workgroup partials (deterministic order)
+// =====================================================================================
+// out[e] = sum_p part[p][e]  (accumulated in double)
+template <typename T>
+__global__ void reduce_parts_kernel(const T* __restrict__ part, int64_t nparts, int64_t len, T* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  double s = 0;
+  for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * len + e];
+  out[e] = (T)s;
+}
+// out[c] = sum_p part[p][c], c < ncomp ; one block
+__global__ void reduce_dparts_kernel(const double* __restrict__ part, int64_t nparts, int ncomp, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  for (int c = 0; c < ncomp; ++c) {
+    double s = 0;
+    for (int64_t p = threadIdx.x; p < nparts; p += blockDim.x) s += part[p * ncomp + c];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[c] = s;
+  }
+}
+// TN slabs: out[b][i][j] = sum_sp slab[sp][b][i][j]; symmetric batches only hold tiles ti >= tj and are mirrored
+template <typename T>
+__global__ void reduce_slabs_kernel(const T* __restrict__ slab, int nsplit, int nbatch, int Mp, int sym, T* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j >= Mp) return;
+  if (sym && (j / GDRF_TILE) > (i / GDRF_TILE)) return;
+  const int64_t mm = (int64_t)Mp * Mp;
+  double s = 0;
+  for (int sp = 0; sp < nsplit; ++sp) s += (double)slab[((int64_t)sp * nbatch + b) * mm + (int64_t)i * Mp + j];
+  out[(int64_t)b * mm + (int64_t)i * Mp + j] = (T)s;
+  if (sym && (j / GDRF_TILE) < (i / GDRF_TILE)) out[(int64_t)b * mm + (int64_t)j * Mp + i] = (T)s;
+}
+
+// =====================================================================================
+// small gradients, Dirichlet term and the loss (one workgroup)
+// red_d: [0] site [1] llw [2] noise_g [3] var_direct [4] knm_k [5] knm_dls ; kuu: [0] kuu_k [1] kuu_dls
+// =====================================================================================
+template <typename T>
+__global__ void grad_small_kernel(int M, int Mp, int K, int V, const Hyper* __restrict__ h, const double* __restrict__ red_d,
+                                  const double* __restrict__ kuu_d, const T* __restrict__ ubar, const T* __restrict__ phibar_lik,
+                                  const T* __restrict__ phi, const double* __restrict__ alpha, double lgam_const,
+                                  double ll_const, double n_global, T* __restrict__ g_hyper3, T* __restrict__ g_uloc,
+                                  T* __restrict__ g_phi, const int* __restrict__ flag, double* __restrict__ out_d) {
+  __shared__ double scratch[16];
+  const double sc = -1.0 / n_global;
+  for (int e = threadIdx.x; e < K * M; e += blockDim.x) {
+    const int k = e / M, i = e - k * M;
+    g_uloc[e] = (T)(sc * (double)ubar[(int64_t)k * Mp + i]);
+  }
+  double lp = 0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double dot = 0;
+    for (int v = 0; v < V; ++v) {
+      const double ph = (double)phi[k * V + v];
+      const double pb = (double)phibar_lik[k * V + v] + (alpha[k * V + v] - 1.0) / ph;
+      dot += ph * pb;
+      lp += (alpha[k * V + v] - 1.0) * log(ph);
+    }
+    for (int v = 0; v < V; ++v) {
+      const double ph = (double)phi[k * V + v];
+      const double pb = (double)phibar_lik[k * V + v] + (alpha[k * V + v] - 1.0) / ph;
+      g_phi[k * V + v] = (T)(sc * ph * (pb - dot));
+    }
+  }
+  lp = block_sum(lp, scratch);
+  if (threadIdx.x == 0) {
+    const double lp_phi = lp + lgam_const;
+    const double elbo_n = red_d[0] + red_d[1] + ll_const + lp_phi;
+    out_d[0] = -elbo_n / n_global;            // loss
+    out_d[1] = (double)(*flag);
+    out_d[2] = red_d[0]; out_d[3] = red_d[1] + ll_const; out_d[4] = lp_phi;
+    g_hyper3[0] = (T)(sc * (red_d[5] + kuu_d[1]));                              // d/d log lengthscale
+    g_hyper3[1] = (T)(sc * (red_d[4] + kuu_d[0] + h->var * red_d[3]));          // d/d log variance
+    g_hyper3[2] = (T)(sc * (h->noise * red_d[2]));                              // d/d log noise
+  }
+}
+
+// =====================================================================================
+// optimizers on the flat unconstrained parameter vector; predicated on the Cholesky flag
+// mode 0 Adam, 1 AdamW (decoupled decay), 2 ClippedAdam
+// =====================================================================================
+template <typename T>
+__global__ void adam_kernel(int64_t n, T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v,
+                            int mode, double lr, double b1, double b2, double eps, double wd, double clip,
+                            double bc1, double bc2, const int* __restrict__ flag) {
+  if (flag && *flag) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double gi = (double)g[i], pi = (double)p[i];
+  if (mode == 2) gi = fmin(fmax(gi, -clip), clip);
+  if (mode == 1) pi *= (1.0 - lr * wd);
+  const double mi = b1 * (double)m[i] + (1.0 - b1) * gi;
+  const double vi = b2 * (double)v[i] + (1.0 - b2) * gi * gi;
+  m[i] = (T)mi; v[i] = (T)vi;
+  if (mode == 2) pi -= lr * sqrt(bc2) / bc1 * mi / (sqrt(vi) + eps);
+  else pi -= (lr / bc1) * mi / (sqrt(vi) / sqrt(bc2) + eps);
+  p[i] = (T)pi;
+}
+
+// =====================================================================================
+// predictive path (mean only): loc_kn = k(x_n, Z) c_k,  c_k = Linv^T u_k
+// =====================================================================================
+template <typename T>
+__global__ void predict_coeff_kernel(const T* __restrict__ Linv, const T* __restrict__ U, int M, int Mp, int K, T* __restrict__ Cf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i >= M) return;
+  double s = 0;
+  for (int j = i; j < M; ++j) s += (double)Linv[(int64_t)j * Mp + i] * (double)U[(int64_t)k * M + j];
+  Cf[(int64_t)k * M + i] = (T)s;
+}
+
+// mode 0: write loc (K,N) ; 1: topic_probs (N,K) ; 2: word_probs (N,V) ; 3: perplexity partial sums
+template <typename T>
+__global__ __launch_bounds__(128) void predict_rows_kernel(const T* __restrict__ X, int64_t nrows, const T* __restrict__ Z, int M, int D,
+                                                           int kind, const Hyper* __restrict__ h, const T* __restrict__ Cf, int K, int V,
+                                                           const T* __restrict__ phi, const int32_t* __restrict__ ws, int mode,
+                                                           T* __restrict__ out, int64_t ldo, double* __restrict__ dpart,
+                                                           int cf_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* scratch = reinterpret_cast<double*>(smem);       // [16]
+  T* Zs = reinterpret_cast<T*>(smem + 128);                // [M*D]
+  T* phiS = Zs + M * D;                                    // [K*V]
+  T* CsL = phiS + K * V;                                   // [K*M] when it fits
+  const T* Cs = cf_in_lds ? CsL : Cf;
+  for (int e = threadIdx.x; e < M * D; e += blockDim.x) Zs[e] = Z[e];
+  if (cf_in_lds) for (int e = threadIdx.x; e < K * M; e += blockDim.x) CsL[e] = Cf[e];
+  if (mode >= 2) for (int e = threadIdx.x; e < K * V; e += blockDim.x) phiS[e] = phi[e];
+  __syncthreads();
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  double s_wlp = 0, s_w = 0;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < nrows; n += (int64_t)gridDim.x * blockDim.x) {
+    T x[GDRF_DMAX];
+#pragma unroll
+    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[n * D + d] : T(0);
+    T lc[GDRF_KMAX];
+#pragma unroll
+    for (int k = 0; k < GDRF_KMAX; ++k) lc[k] = 0;
+    for (int i = 0; i < M; ++i) {
+      T r2 = 0;
+#pragma unroll
+      for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Zs[i * D + d]; r2 += t * t; }
+      const T kv = cov_from_r2<T>(kind, r2 * ils2, var);
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) lc[k] += kv * Cs[k * M + i];
+    }
+    if (mode == 0) {
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) out[(int64_t)k * ldo + n] = lc[k];
+      continue;
+    }
+    T mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) mx = fmax(mx, lc[k]);
+    T se = 0;
+#pragma unroll
+    for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) { lc[k] = t_exp<T>(lc[k] - mx); se += lc[k]; }
+    const T ise = T(1) / se;
+#pragma unroll
+    for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) lc[k] *= ise;
+    if (mode == 1) {
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) out[n * ldo + k] = lc[k];
+      continue;
+    }
+    for (int v = 0; v < V; ++v) {
+      T p = 0;
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) p += lc[k] * phiS[k * V + v];
+      if (mode == 2) out[n * ldo + v] = p;
+      else { const double w = (double)ws[n * V + v]; s_wlp += w * (double)t_log<T>(p); s_w += w; }
+    }
+  }
+  if (mode == 3) {
+    const double a = block_sum(s_wlp, scratch), b = block_sum(s_w, scratch);
+    if (threadIdx.x == 0) { dpart[2 * (int64_t)blockIdx.x] = a; dpart[2 * (int64_t)blockIdx.x + 1] = b; }
+  }
+}
+
+// =====================================================================================
+// data-only Multinomial constant: sum_n [lgamma(sum_v w + 1) - sum_v lgamma(w + 1)]  
+// =====================================================================================
+__global__ void ll_const_kernel(const int32_t* __restrict__ ws, int64_t nrows, int V, double* __restrict__ dpart) {
+  __shared__ double scratch[16];
+  double s = 0;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < nrows; n += (int64_t)gridDim.x * blockDim.x) {
+    double tot = 0, sl = 0;
+    for (int v = 0; v < V; ++v) { const double w = (double)ws[n * V + v]; tot += w; sl += lgamma(w + 1.0); }
+    s += lgamma(tot + 1.0) - sl;
+  }
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) dpart[blockIdx.x] = s;
+}
+
+// =====================================================================================
+// counter-based standard normals: Philox4x32-10 keyed by (seed), counter (global row, topic, step)
+// -> identical draws for any sharding of the rows over ranks
+// =====================================================================================
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+template <typename T>
+__global__ void fill_eps_kernel(uint64_t seed, uint32_t step, int64_t n_offset, int64_t nrows, int K, T* __restrict__ eps, int64_t ldk) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (n >= nrows) return;
+  const uint64_t gn = (uint64_t)(n + n_offset);
+  uint32_t c[4] = {(uint32_t)gn, (uint32_t)(gn >> 32), (uint32_t)k, step};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  const double u1 = ((double)c[0] + 0.5) * (1.0 / 4294967296.0);
+  const double u2 = ((double)c[1] + 0.5) * (1.0 / 4294967296.0);
+  eps[(int64_t)k * ldk + n] = (T)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+}
+
+}  // namespace gdrf

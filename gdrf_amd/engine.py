@@ -1,0 +1,266 @@
+"""Host-side driver of libgdrf_hip: owns the device context, the flat unconstrained-parameter /
+gradient / optimizer-state buffers (PyTorch-ROCm tensors used as storage only) and sequences one
+SVI step:  factorize (jitter retry) -> step_local -> [RCCL all-reduce] -> step_finish -> adam.
+
+Reference behaviour mirrored here (paths under /root/reference):
+  jittercholesky retry schedule        gdrf/models/utils.py:27-40
+  SVI.step / 1/N scaling               gdrf/train_script.py:365-371,467
+  parameter initialisation             gdrf/models/sparse_gdrf.py:96-122, abstract_gdrf.py:57-84
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+KERNEL_IDS = {"rbf": 0, "matern52": 1}
+OPT_MODES = {"adam": 0, "adamw": 1, "clippedadam": 2}
+
+_WS_IDS = dict(W=0, Wbar=1, q=2, loc=3, tt=4, vbar=5, locbar=6, asum=7, Kuu=8, L=9, Linv=10, S=11, B=12, phi=13,
+               mu=14, LinvT=15, ST=16)
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Engine:
+    """One device context for fixed (n_cap, M, K, V, D, dtype, kernel)."""
+
+    def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
+                 device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.GdrfHipError(f"gdrf_amd runs on a HIP device only, got device={device!r}")
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        self.dtype = dtype
+        self.n_cap, self.M, self.K, self.V, self.D = int(n_cap), int(M), int(K), int(V), int(D)
+        self.kernel = kernel
+        self.jitter, self.maxjitter = float(jitter), int(maxjitter)
+        self.pg = process_group          # "auto": default group when torch.distributed is initialised; None: never reduce
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        torch.cuda.set_device(dev_index)
+        ctx = C.c_void_p()
+        _lib.check(self.lib.gdrf_ctx_create(C.byref(ctx), dev_index, self.n_cap, self.M, self.K, self.V, self.D,
+                                            0 if dtype == torch.float32 else 1, KERNEL_IDS[kernel]), "gdrf_ctx_create")
+        self.ctx = ctx
+        lay = (C.c_int64 * 7)()
+        _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
+        self.layout = dict(log_lengthscale=lay[0], log_variance=lay[1], log_noise=lay[2], u_loc=lay[3], phi_unc=lay[4],
+                           u_scale_tril_unc=lay[5], total=lay[6])
+        red = (C.c_int64 * 6)()
+        _lib.check(self.lib.gdrf_red_layout(self.ctx, red), "gdrf_red_layout")
+        self.red_layout = dict(ubar=red[0], phibar=red[1], A=red[2], GT=red[3], total_T=red[4], total_d=red[5])
+        z = lambda n, dt: torch.zeros(int(n), dtype=dt, device=self.device)
+        self.params = z(lay[6], dtype)
+        self.grads = z(lay[6], dtype)
+        self.exp_avg = z(lay[6], dtype)
+        self.exp_avg_sq = z(lay[6], dtype)
+        self.red_T = z(red[4], dtype)
+        self.red_d = z(red[5], torch.float64)
+        self.out_d = z(8, torch.float64)
+        self.Z: Optional[torch.Tensor] = None
+        self.opt_step = 0
+        self.last_jitter_level = 0
+        self._ll_cache = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.gdrf_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ---- parameter views (natural shapes) ---------------------------------------------------------
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        buf = self.params if buf is None else buf
+        o = self.layout[name]
+        K, M, V = self.K, self.M, self.V
+        if name in ("log_lengthscale", "log_variance", "log_noise"):
+            return buf[o:o + 1].view(())
+        if name == "u_loc":
+            return buf[o:o + K * M].view(K, M)
+        if name == "phi_unc":
+            return buf[o:o + K * V].view(K, V)
+        if name == "u_scale_tril_unc":
+            return buf[o:o + K * M * M].view(K, M, M)
+        raise KeyError(name)
+
+    PARAM_NAMES = ("log_lengthscale", "log_variance", "log_noise", "u_loc", "phi_unc", "u_scale_tril_unc")
+
+    def named_views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        return {n: self.view(n, buf) for n in self.PARAM_NAMES}
+
+    def set_inducing_points(self, Z: torch.Tensor):
+        Z = Z.to(device=self.device, dtype=self.dtype).contiguous()
+        assert Z.shape == (self.M, self.D), f"inducing points must be ({self.M},{self.D}), got {tuple(Z.shape)}"
+        self.Z = Z
+
+    def set_dirichlet(self, alpha: torch.Tensor):
+        a = alpha.detach().to("cpu", torch.float64).contiguous()
+        assert a.shape == (self.K, self.V)
+        arr = (C.c_double * (self.K * self.V))(*a.flatten().tolist())
+        _lib.check(self.lib.gdrf_set_dirichlet(self.ctx, arr), "gdrf_set_dirichlet")
+
+    # ---- workspace access for parity tests ----------------------------------------------------------
+    def workspace(self, name: str, n_rows: Optional[int] = None) -> torch.Tensor:
+        """Copy of a workspace buffer in its natural (unpadded) shape."""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.gdrf_ws_ptr(self.ctx, _WS_IDS[name], C.byref(ptr), C.byref(cnt)), "gdrf_ws_ptr")
+        flat = torch.empty(cnt.value, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.gdrf_ws_copy(self.ctx, _WS_IDS[name], flat.data_ptr(), cnt.value, _stream_ptr(self.device)),
+                   "gdrf_ws_copy")
+        torch.cuda.synchronize(self.device)
+        Mp = (self.M + 31) // 32 * 32
+        ldk = (self.n_cap + 3) // 4 * 4
+        n = self.n_cap if n_rows is None else n_rows
+        if name in ("W", "Wbar"):
+            return flat.view(self.n_cap, Mp)[:n, :self.M].clone()
+        if name in ("q", "asum"):
+            return flat[:n].clone()
+        if name in ("loc", "tt", "vbar", "locbar", "mu"):
+            return flat.view(self.K, ldk)[:, :n].clone()
+        if name in ("Kuu", "L", "Linv", "LinvT"):
+            return flat.view(Mp, Mp)[:self.M, :self.M].clone()
+        if name in ("S", "B", "ST"):
+            return flat.view(self.K, Mp, Mp)[:, :self.M, :self.M].clone()
+        if name == "phi":
+            return flat.view(self.K, self.V).clone()
+        raise KeyError(name)
+
+    # ---- primitives ------------------------------------------------------------------------------
+    def _chk_rows(self, xs: torch.Tensor, ws: Optional[torch.Tensor] = None):
+        if xs.device != self.device or xs.dtype != self.dtype or not xs.is_contiguous() or xs.dim() != 2 or xs.shape[1] != self.D:
+            raise ValueError(f"xs must be a contiguous ({'n'},{self.D}) {self.dtype} tensor on {self.device}")
+        if ws is not None:
+            if ws.device != self.device or ws.dtype != torch.int32 or not ws.is_contiguous() or ws.shape != (xs.shape[0], self.V):
+                raise ValueError(f"ws must be a contiguous (n,{self.V}) int32 tensor on {self.device}")
+
+    def knm(self, xs: torch.Tensor) -> torch.Tensor:
+        """K_nm = k(xs, Z) (n, M) row-major: the HBM-roofline kernel."""
+        self._chk_rows(xs)
+        out = torch.empty(xs.shape[0], self.M, dtype=self.dtype, device=self.device)
+        self.knm_into(xs, out)
+        return out
+
+    def knm_into(self, xs: torch.Tensor, out: torch.Tensor):
+        _lib.check(self.lib.gdrf_knm(self.ctx, xs.data_ptr(), xs.shape[0], self.Z.data_ptr(), self.params.data_ptr(),
+                                     out.data_ptr(), out.shape[1], _stream_ptr(self.device)), "gdrf_knm")
+
+    def fill_eps(self, seed: int, step: int, n_offset: int, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.K, n, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.gdrf_fill_eps(self.ctx, seed & (2 ** 64 - 1), step & 0xFFFFFFFF, n_offset, n, out.data_ptr(),
+                                          _stream_ptr(self.device)), "gdrf_fill_eps")
+        return out
+
+    def ll_const(self, ws: torch.Tensor) -> float:
+        key = (ws.data_ptr(), ws._version, tuple(ws.shape))
+        if self._ll_cache is not None and self._ll_cache[0] == key:
+            return self._ll_cache[1]
+        out = C.c_double()
+        _lib.check(self.lib.gdrf_ll_const(self.ctx, ws.data_ptr(), ws.shape[0], C.byref(out), _stream_ptr(self.device)),
+                   "gdrf_ll_const")
+        self._ll_cache = (key, out.value)
+        return out.value
+
+    def jitter_total(self, level: int) -> float:
+        return sum(self.jitter * (10 ** n) for n in range(level + 1))
+
+    def factorize(self, force_level: Optional[int] = None) -> int:
+        """jittercholesky: smallest level whose cumulative jitter gives a positive-definite K_uu
+        (every call starts from level 0, as the reference rebuilds K_uu each time)."""
+        s = _stream_ptr(self.device)
+        failed = C.c_int()
+        level = 0 if force_level is None else force_level
+        while level < self.maxjitter:
+            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(level), s),
+                       "gdrf_factorize")
+            _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), s), "gdrf_chol_failed")
+            if not failed.value:
+                self.last_jitter_level = level
+                return level
+            if force_level is not None:
+                break
+            level += 1
+        raise RuntimeError("reached max jitter, covariance is unstable")
+
+    def loss_and_grads(self, xs, ws, eps, n_global: Optional[int] = None, ll_const: Optional[float] = None,
+                       force_level: Optional[int] = None):
+        """One ELBO evaluation + backward.  Leaves d loss/d unconstrained in self.grads (device) and
+        returns nothing host-side; call read_out() for the loss."""
+        self._chk_rows(xs, ws)
+        n = xs.shape[0]
+        if eps.shape != (self.K, n) or eps.dtype != self.dtype or not eps.is_contiguous() or eps.device != self.device:
+            raise ValueError(f"eps must be a contiguous ({self.K},{n}) {self.dtype} tensor on {self.device}")
+        s = _stream_ptr(self.device)
+        self.factorize(force_level)
+        _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps.data_ptr(), n, self.Z.data_ptr(),
+                                            self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
+                   "gdrf_step_local")
+        llc = self.ll_const(ws) if ll_const is None else ll_const
+        ng = float(n if n_global is None else n_global)
+        if self._distributed():
+            import torch.distributed as dist
+            pg = None if isinstance(self.pg, str) else self.pg
+            self.red_d[6] = llc                      # the data constant is a sum over observations too
+            dist.all_reduce(self.red_T, group=pg)    # RCCL over xGMI (backend "nccl" on ROCm)
+            dist.all_reduce(self.red_d, group=pg)
+            llc = None
+        self._finish(ng, llc)
+
+    def _distributed(self) -> bool:
+        if self.pg is None:
+            return False
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        pg = None if isinstance(self.pg, str) else self.pg
+        return dist.get_world_size(pg) > 1
+
+    def _finish(self, n_global: float, ll_const: Optional[float]):
+        s = _stream_ptr(self.device)
+        if ll_const is None:                         # reduced copy travels in red_d[6]
+            ll_const = float(self.red_d[6].item())
+        _lib.check(self.lib.gdrf_step_finish(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.red_T.data_ptr(),
+                                             self.red_d.data_ptr(), n_global, ll_const, self.grads.data_ptr(),
+                                             self.out_d.data_ptr(), s), "gdrf_step_finish")
+
+    def adam(self, mode: str, lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=10.0):
+        self.opt_step += 1
+        _lib.check(self.lib.gdrf_adam(self.ctx, OPT_MODES[mode], self.params.data_ptr(), self.grads.data_ptr(),
+                                      self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.opt_step, lr, betas[0], betas[1],
+                                      eps, weight_decay, clip, _stream_ptr(self.device)), "gdrf_adam")
+
+    def read_out(self) -> Dict[str, float]:
+        o = self.out_d.cpu().tolist()          # synchronises
+        return dict(loss=o[0], chol_failed=o[1], site=o[2], loglik=o[3], lp_phi=o[4])
+
+    def predict(self, xs: torch.Tensor, mode: int, ws: Optional[torch.Tensor] = None):
+        self._chk_rows(xs, ws)
+        n = xs.shape[0]
+        self.factorize()
+        out = None
+        if mode == 0:
+            out = torch.empty(self.K, n, dtype=self.dtype, device=self.device)
+        elif mode == 1:
+            out = torch.empty(n, self.K, dtype=self.dtype, device=self.device)
+        elif mode == 2:
+            out = torch.empty(n, self.V, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.gdrf_predict(self.ctx, xs.data_ptr(), n, self.Z.data_ptr(), self.params.data_ptr(),
+                                         ws.data_ptr() if ws is not None else None, mode,
+                                         out.data_ptr() if out is not None else None, self.out_d.data_ptr(),
+                                         _stream_ptr(self.device)), "gdrf_predict")
+        if mode == 3:
+            return self.out_d[:2].clone()
+        return out

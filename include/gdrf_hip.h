@@ -1,0 +1,101 @@
+/* libgdrf_hip: C ABI of the MI355X-native GDRF SVI ELBO hot path.
+ *
+ * The reference (san-soucie/gdrf v0.1.3) is pure Python and has no FFI; the seam this library
+ * sits behind is the duck-typed Python surface of SURVEY.md 8(b).  Each entry point below names
+ * the reference code (paths under /root/reference) whose work it replaces; the Python mirror in
+ * gdrf_amd/ binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every function returns 0 on success, < 0 on a HIP/argument error (message from
+ * gdrf_last_error()); pointers named *_dev are borrowed device pointers that the caller keeps
+ * alive until the stream has been synchronised; `stream` is a hipStream_t passed as void*;
+ * no exceptions cross the ABI; one host thread per context.  dtype: 0 = f32, 1 = f64 (the
+ * element type of every "void*" real array below).  kernel_id: 0 = RBF, 1 = Matern52.
+ */
+#ifndef GDRF_HIP_H
+#define GDRF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gdrf_ctx gdrf_ctx;
+
+enum { GDRF_F32 = 0, GDRF_F64 = 1 };
+enum { GDRF_RBF = 0, GDRF_MATERN52 = 1 };
+enum { GDRF_ADAM = 0, GDRF_ADAMW = 1, GDRF_CLIPPED_ADAM = 2 };
+enum { GDRF_PRED_LOC = 0, GDRF_PRED_TOPIC_PROBS = 1, GDRF_PRED_WORD_PROBS = 2, GDRF_PRED_PERPLEXITY = 3 };
+
+const char* gdrf_last_error(void);
+int gdrf_version(void);
+
+/* Workspaces for at most n_cap local observations.  Replaces the tensors pyro/autograd allocate
+ * per step inside SVI.step (gdrf/train_script.py:365-371,467). */
+int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id);
+void gdrf_ctx_destroy(gdrf_ctx* ctx);
+
+/* Flat unconstrained-parameter vector (the PyroParam storage of gdrf/models/sparse_gdrf.py:96-122
+ * and the pyro kernel's lengthscale/variance): out = {off_log_lengthscale, off_log_variance,
+ * off_log_noise, off_u_loc (K*M), off_phi_unc (K*V), off_u_scale_tril_unc (K*M*M), total}. */
+int gdrf_param_layout(const gdrf_ctx* ctx, int64_t out[7]);
+/* Per-step all-reduce payload: out = {off_ubar, off_phibar, off_A, off_GT, total_T, total_d}. */
+int gdrf_red_layout(const gdrf_ctx* ctx, int64_t out[6]);
+/* Dirichlet concentration (K*V doubles, host): validate_dirichlet_param, gdrf/models/utils.py:6-24. */
+int gdrf_set_dirichlet(gdrf_ctx* ctx, const double* alpha_host);
+
+/* K_nm = k(X, Z), row-major (n, ldo): pyro RBF/Matern52.forward(X, Z) as used inside
+ * gp.util.conditional (gdrf/models/sparse_gdrf.py:334-344).  The HBM-roofline kernel. */
+int gdrf_knm(gdrf_ctx* ctx, const void* X_dev, int64_t n, const void* Z_dev, const void* params_dev,
+             void* out_dev, int64_t ldo, void* stream);
+
+/* eps[k][n] ~ N(0,1), Philox keyed by (seed; global row n_offset+n, k, step): the rsample of the
+ * guide's mu site (gdrf/models/sparse_gdrf.py:403-405). */
+int gdrf_fill_eps(gdrf_ctx* ctx, uint64_t seed, uint32_t step, int64_t n_offset, int64_t n, void* eps_dev, void* stream);
+
+/* sum_n [lgamma(sum_v w+1) - sum_v lgamma(w+1)]: the data-only part of Multinomial.log_prob
+ * (gdrf/models/sparse_gdrf.py:363-372).  Synchronises the stream. */
+int gdrf_ll_const(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* out_host, void* stream);
+
+/* K_uu = k(Z,Z) + jitter_total*I, its Cholesky factor L and L^{-1}, kept in the context for the
+ * calls below: one attempt of jittercholesky (gdrf/models/utils.py:27-40) on
+ * kernel(inducing_points) (gdrf/models/sparse_gdrf.py:327-328,382-383).  A non-positive pivot is
+ * reported by gdrf_chol_failed(); the host then retries with the next cumulative jitter. */
+int gdrf_factorize(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream);
+
+/* Forward + backward over this rank's n_local observations: everything of one
+ * SVI.step(xs, ws) (gdrf/train_script.py:467 -> sparse_gdrf.py:323-409) that is a sum over
+ * observations.  X (n,D), ws (n,V) int32, eps (K,n).  Writes the partial sums to red_T
+ * (dtype elements) and red_d (doubles); the caller all-reduces both over ranks.  Needs gdrf_factorize() on the same params. */
+int gdrf_step_local(gdrf_ctx* ctx, const void* X_dev, const int32_t* ws_dev, const void* eps_dev, int64_t n_local,
+                    const void* Z_dev, const void* params_dev, void* red_T_dev, double* red_d_dev, void* stream);
+
+/* Replicated epilogue: Cholesky / kernel hyper-parameter backward, constraint Jacobians, Dirichlet
+ * term, loss.  grads (same layout as params) = d loss / d unconstrained.  out_d (8 doubles) =
+ * {loss, cholesky_failed, site_sum, loglik_sum, log_prior_phi, ...}. */
+int gdrf_step_finish(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const void* red_T_dev,
+                     const double* red_d_dev, double n_global, double ll_const, void* grads_dev, double* out_d_dev,
+                     void* stream);
+
+/* pyro.optim.{Adam,AdamW,ClippedAdam} on every unconstrained tensor at once (train_script.py:73-87);
+ * skipped on the device when the step's Cholesky failed. t = 1-based step count. */
+int gdrf_adam(gdrf_ctx* ctx, int mode, void* params_dev, const void* grads_dev, void* m_dev, void* v_dev, int64_t t,
+              double lr, double beta1, double beta2, double eps, double weight_decay, double clip, void* stream);
+
+/* Predictive mean path: log_topic_probs / topic_probs / word_probs / perplexity
+ * (gdrf/models/sparse_gdrf.py:161-186, abstract_gdrf.py:113-139).  mode 0: out (K,n) ;
+ * 1: out (n,K) ; 2: out (n,V) ; 3: out_d_dev[0..1] = {sum w log p, sum w}.  Needs gdrf_factorize(). */
+int gdrf_predict(gdrf_ctx* ctx, const void* X_dev, int64_t n, const void* Z_dev, const void* params_dev,
+                 const int32_t* ws_dev, int mode, void* out_dev, double* out_d_dev, void* stream);
+
+/* Did the last gdrf_factorize() hit a non-positive pivot?  Synchronises the stream. */
+int gdrf_chol_failed(gdrf_ctx* ctx, int* failed_host, void* stream);
+
+/* Borrowed pointers into the workspace (for parity tests): which = 0 W, 1 Wbar, 2 q, 3 loc, 4 tt,
+ * 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST. */
+int gdrf_ws_ptr(gdrf_ctx* ctx, int which, void** ptr, int64_t* nelem);
+/* Device-to-device copy of the first nelem elements of that buffer into dst_dev. */
+int gdrf_ws_copy(gdrf_ctx* ctx, int which, void* dst_dev, int64_t nelem, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
