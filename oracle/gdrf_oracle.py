@@ -234,7 +234,8 @@ class RefShapedGDRF:
         probs = torch.matmul(topic_probs, c["phi"])
         ll = Multinomial(probs=probs, validate_args=False).log_prob(ws).sum()
         elbo = scale * (lp_mu + lp_phi + ll - lq_mu)
-        self.last_terms = dict(lp_mu=float(lp_mu), lq_mu=float(lq_mu), lp_phi=float(lp_phi), ll=float(ll))
+        self.last_terms = dict(lp_mu=float(lp_mu.detach()), lq_mu=float(lq_mu.detach()), lp_phi=float(lp_phi.detach()),
+                               ll=float(ll.detach()))
         return -elbo
 
     def loss_and_grads(self, eps, **kw) -> Tuple[float, Dict[str, torch.Tensor]]:
@@ -242,7 +243,7 @@ class RefShapedGDRF:
             p.grad = None
         loss = self.loss(eps, **kw)
         loss.backward()
-        return float(loss), {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
+        return float(loss.detach()), {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
                              for k, p in self.params.items()}
 
     # ---- optimizers: one instance per parameter -----------------
@@ -458,7 +459,7 @@ def synth_circles(W: int, H: int, V: int, K: int, *, n_discs=8, R_frac=0.1, eta=
         centers = rng.uniform(0.1, 0.9, size=(n_discs, 2))
     N = xs.shape[0]
     K_obj = K - 1
-    obj_topics = rng.integers(0, K_obj, size=n_discs)
+    obj_topics = rng.integers(0, K_obj, size=n_discs) if K_obj > 0 else np.full(n_discs, K - 1)
     p_v_z = np.full((K, V), eta)
     for k in range(K_obj):
         lo, hi = V * k / K_obj, V * (k + 1) / K_obj

@@ -1,0 +1,52 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import numpy as np
+import torch
+
+from oracle.gdrf_oracle import RefShapedGDRF, fused_elbo_and_grads, jitter_total, synth_circles
+
+NAME_MAP = dict(log_lengthscale="log_lengthscale", log_variance="log_variance", log_noise="log_noise",
+                u_loc="u_loc", phi_unc="phi_unc", u_scale_tril_unc="u_scale_tril_unc")
+
+
+def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.float64, seed=1, jitter=1e-6,
+                perturb=True, one_d=False, optimizer="adam", lr=1e-3, force_jitter_level=None, lengthscale=0.1):
+    xs, ws, _ = synth_circles(W, H, V, K, seed=seed, one_d=one_d)
+    m = RefShapedGDRF(xs, ws, kind=kind, K=K, n_points=n_points, dtype=dtype, jitter=jitter, optimizer=optimizer, lr=lr,
+                      force_jitter_level=force_jitter_level, lengthscale=lengthscale)
+    g = torch.Generator().manual_seed(seed + 100)
+    if perturb:
+        with torch.no_grad():
+            m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64).to(dtype))
+            m.params["u_scale_tril_unc"].add_(
+                0.1 * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril().to(dtype))
+            m.params["phi_unc"].add_(0.5 * torch.randn(m.params["phi_unc"].shape, generator=g, dtype=torch.float64).to(dtype))
+            m.params["log_noise"].add_(0.2)
+    eps = torch.randn(K, m.N, generator=g, dtype=torch.float64).to(dtype)
+    return m, eps
+
+
+def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None):
+    """gdrf_amd.Engine holding exactly the oracle's parameters / inducing points / Dirichlet prior."""
+    from gdrf_amd.engine import Engine
+    dtype = m.dtype if dtype is None else dtype
+    eng = Engine(n_cap or m.N, m.M, m.K, m.V, m.D, dtype=dtype, kernel=m.kind, device=device, jitter=m.jitter,
+                 maxjitter=m.maxjitter, process_group=None)
+    eng.set_inducing_points(m.Z)
+    eng.set_dirichlet(m.alpha)
+    load_params(eng, m)
+    return eng
+
+
+def load_params(eng, m):
+    for name in eng.PARAM_NAMES:
+        eng.view(name).copy_(m.params[name].detach().to(eng.dtype))
+
+
+def dev(t, eng, dtype=None):
+    return torch.as_tensor(t).to(device=eng.device, dtype=dtype or eng.dtype).contiguous()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
