@@ -32,6 +32,8 @@ SIGNATURES = {
     "gdrf_chol_failed": (_int, [_vp, C.POINTER(_int), _vp]),
     "gdrf_ws_ptr": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_i64)]),
     "gdrf_ws_copy": (_int, [_vp, _int, _vp, _i64, _vp]),
+    "gdrf_set_timing": (_int, [_vp, _int]),
+    "gdrf_get_timing": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64), _int]),
 }
 
 _lib = None

@@ -31,6 +31,7 @@ static int fail(int code, const char* what, const char* detail) {
     if (e_ != hipSuccess) return fail(-(int)e_ - 1000, name, hipGetErrorString(e_)); \
   } while (0)
 
+#define GDRF_NSLOTS 16
 struct gdrf_ctx {
   int dev, M, Mp, K, V, D, dtype, kind;
   int64_t ncap, ldk;          // ldk = leading dimension of the (K, n) arrays
@@ -49,6 +50,26 @@ struct gdrf_ctx {
   double* alpha_dev; double lgam_const;
   Hyper* hyp; int* flag;
   std::vector<void*> allocs;
+  // optional per-kernel HIP-event timing (gdrf_set_timing): events recorded on the launch stream
+  int timing;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;   // (slot, (start, stop)) pending
+  std::vector<hipEvent_t> ev_pool;
+  double t_ms[GDRF_NSLOTS]; int64_t t_cnt[GDRF_NSLOTS];
+};
+
+struct ScopedTimer {
+  gdrf_ctx* c; int slot; hipStream_t s; hipEvent_t e0, e1; bool on;
+  ScopedTimer(gdrf_ctx* c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_), on(c_->timing != 0) {
+    if (!on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    e0 = get(); e1 = get();
+    (void)hipEventRecord(e0, s);
+  }
+  ~ScopedTimer() {
+    if (!on) return;
+    (void)hipEventRecord(e1, s);
+    c->tev.push_back({slot, {e0, e1}});
+  }
 };
 
 const char* gdrf_last_error(void) { return g_err.c_str(); }
@@ -98,7 +119,8 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   c->dtype = dtype; c->kind = kernel_id; c->ncap = n_cap; c->ldk = round_up(n_cap, 4);
   c->esz = dtype == GDRF_F32 ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
-  c->lgam_const = 0; c->alpha_dev = nullptr;
+  c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
+  for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz;
   auto A = [&](void** p, size_t bytes) -> int {
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
@@ -141,6 +163,8 @@ void gdrf_ctx_destroy(gdrf_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
   for (void* p : c->allocs) (void)hipFree(p);
+  for (auto& t : c->tev) { (void)hipEventDestroy(t.second.first); (void)hipEventDestroy(t.second.second); }
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -180,6 +204,25 @@ int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) {
   return 0;
 }
 
+int gdrf_set_timing(gdrf_ctx* c, int enable) {
+  c->timing = enable;
+  for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
+  return 0;
+}
+int gdrf_get_timing(gdrf_ctx* c, double* ms_out, int64_t* cnt_out, int nslots) {
+  HIPCHK(hipSetDevice(c->dev));
+  for (auto& t : c->tev) {
+    HIPCHK(hipEventSynchronize(t.second.second));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, t.second.first, t.second.second));
+    c->t_ms[t.first] += ms; c->t_cnt[t.first] += 1;
+    c->ev_pool.push_back(t.second.first); c->ev_pool.push_back(t.second.second);
+  }
+  c->tev.clear();
+  for (int i = 0; i < nslots && i < GDRF_NSLOTS; ++i) { ms_out[i] = c->t_ms[i]; cnt_out[i] = c->t_cnt[i]; }
+  return 0;
+}
+
 int gdrf_ws_copy(gdrf_ctx* c, int which, void* dst, int64_t nelem, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   void* p; int64_t n;
@@ -208,6 +251,7 @@ template <typename T> struct Impl {
   // hyper -> Kuu(+jitter) -> Cholesky(flag) -> L, LT -> Linv, LinvT
   static int prologue(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
     const int Mp = c->Mp, M = c->M;
+    ScopedTimer tm(c, 0, s);
     HIPCHK(hipMemsetAsync(c->flag, 0, 16, s));
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     dim3 g2((Mp + 255) / 256, Mp);
@@ -223,6 +267,7 @@ template <typename T> struct Impl {
 
   static int knm(gdrf_ctx* c, const T* X, int64_t n, const T* Z, const T* params, T* out, int64_t ldo, hipStream_t s) {
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
+    ScopedTimer tm(c, 1, s);
     const int VE = Vec16<T>::N;
     const int64_t total = n * ((c->M + VE - 1) / VE);
     int64_t blocks = (total + 255) / 256;
@@ -242,24 +287,30 @@ template <typename T> struct Impl {
     const T* U = params + poff(c, 3);
     const T* phi_unc = params + poff(c, 4);
     const T* Sunc = params + poff(c, 5);
-    dim3 g3((Mp + 255) / 256, Mp, K);
-    hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
-    hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
-    if ((rc = mm_nt(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
+    {
+      ScopedTimer tm(c, 2, s);
+      dim3 g3((Mp + 255) / 256, Mp, K);
+      hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
+      hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
+      if ((rc = mm_nt(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
+    }
 
     const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
     // (1) W = Knm Linv^T
     {
+      ScopedTimer tm(c, 3, s);
       FwdWProb<T> p{X, n, Z, M, Mp, c->D, c->kind, c->hyp, P(c->Linv), P(c->W)};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdWProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), C::LDS_BYTES, s, p);
     }
     // q, loc
     {
+      ScopedTimer tm(c, 4, s);
       int64_t blocks = (n + 3) / 4; if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(rowstats_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, P(c->W), n, M, Mp, K, U, P(c->q), P(c->loc), ldk);
     }
     // (2) tt_kn = ||S_k^T w_n||^2
     {
+      ScopedTimer tm(c, 5, s);
       FwdTProb<T> p{P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
     }
@@ -267,6 +318,7 @@ template <typename T> struct Impl {
     // per-row ELBO terms and row-local backward
     int egrid;
     {
+      ScopedTimer tm(c, 6, s);
       int RB = 128;
       size_t lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T);
       if (lds > 150 * 1024) { RB = 64; lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T); }
@@ -284,11 +336,13 @@ template <typename T> struct Impl {
     }
     // (3) Wbar
     {
+      ScopedTimer tm(c, 7, s);
       BwdWbarProb<T> p{P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
       hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), C::LDS_BYTES, s, p);
     }
     // (4) kernel hyper-parameter partials through Knm
     {
+      ScopedTimer tm(c, 8, s);
       BwdKnmProb<T> p{P(c->Wbar), n, M, Mp, c->D, c->kind, P(c->LinvT), X, Z, c->hyp, c->dpart};
       const int64_t nb = rtiles * c->nt;
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
@@ -302,16 +356,21 @@ template <typename T> struct Impl {
       const int ns = tn_nsplit(c, n, BR);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
       TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K};
-      hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * (c->nt + 1) / 2, K, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, a);
-      dim3 gr((Mp + 255) / 256, Mp, K);
-      hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2));
+      { ScopedTimer tm(c, 9, s);
+        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * (c->nt + 1) / 2, K, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, a); }
+      { ScopedTimer tm(c, 11, s);
+        dim3 gr((Mp + 255) / 256, Mp, K);
+        hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2)); }
       TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, P(c->slab), 1};
-      hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * c->nt, 1, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, b);
-      dim3 gr1((Mp + 255) / 256, Mp, 1);
-      hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, s, P(c->slab), ns, 1, Mp, 0, redT + roff(c, 3));
+      { ScopedTimer tm(c, 10, s);
+        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * c->nt, 1, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, b); }
+      { ScopedTimer tm(c, 11, s);
+        dim3 gr1((Mp + 255) / 256, Mp, 1);
+        hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, s, P(c->slab), ns, 1, Mp, 0, redT + roff(c, 3)); }
     }
     // (6) ubar
     {
+      ScopedTimer tm(c, 12, s);
       const int64_t nb = (n + 2047) / 2048;
       hipLaunchKernelGGL(ubar_part_kernel<T>, dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, s, P(c->W), n, Mp, K, P(c->locbar),
                          ldk, (int64_t)2048, P(c->ubar_part));
@@ -331,6 +390,7 @@ template <typename T> struct Impl {
     const T* phib = redT + roff(c, 1);
     const T* Ak = redT + roff(c, 2);
     const T* GT = redT + roff(c, 3);
+    ScopedTimer tm(c, 13, s);
     dim3 g2((Mp + 255) / 256, Mp);
     // HT = GT Linv ; LbarT = -triu(HT)
     if ((rc = mm_nt(c, GT, 0, P(c->LinvT), 0, P(c->t0), 0, T(1), 1, s))) return rc;
@@ -438,6 +498,7 @@ int gdrf_adam(gdrf_ctx* c, int mode, void* params, const void* grads, void* m, v
   const int64_t n = poff(c, 6);
   const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
   dim3 grid((unsigned)((n + 255) / 256));
+  ScopedTimer tm(c, 14, s);
   if (c->dtype == GDRF_F32)
     hipLaunchKernelGGL(adam_kernel<float>, grid, dim3(256), 0, s, n, (float*)params, (const float*)grads, (float*)m, (float*)v, mode, lr,
                        b1, b2, eps, wd, clip, bc1, bc2, (const int*)c->flag);

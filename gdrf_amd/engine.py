@@ -138,6 +138,18 @@ class Engine:
             return flat.view(self.K, self.V).clone()
         raise KeyError(name)
 
+    TIMING_SLOTS = ("factorize", "k_nm", "transforms", "fwd_w", "rowstats", "fwd_t", "elbo_rows", "bwd_wbar", "bwd_knm",
+                    "tn_sym", "tn_gt", "slab_reduce", "ubar", "step_finish", "adam")
+
+    def set_timing(self, enable: bool):
+        _lib.check(self.lib.gdrf_set_timing(self.ctx, 1 if enable else 0), "gdrf_set_timing")
+
+    def get_timing(self) -> Dict[str, Dict[str, float]]:
+        n = len(self.TIMING_SLOTS)
+        ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+        _lib.check(self.lib.gdrf_get_timing(self.ctx, ms, cnt, n), "gdrf_get_timing")
+        return {name: dict(ms=ms[i], count=cnt[i]) for i, name in enumerate(self.TIMING_SLOTS)}
+
     # ---- primitives ------------------------------------------------------------------------------
     def _chk_rows(self, xs: torch.Tensor, ws: Optional[torch.Tensor] = None):
         if xs.device != self.device or xs.dtype != self.dtype or not xs.is_contiguous() or xs.dim() != 2 or xs.shape[1] != self.D:

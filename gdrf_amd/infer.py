@@ -1,0 +1,107 @@
+"""``pyro.infer.SVI`` / ``Trace_ELBO`` / ``TraceGraph_ELBO`` as used by gdrf/train_script.py:88-92,
+330-335,365-371,467:  ``svi.step(xs=, ws=, subsample=False) -> float`` (loss = -ELBO, every site
+scaled by the poutine.scale factor).
+
+For ``SparseMultinomialGDRF`` every guide site is reparameterised, so Trace_ELBO and
+TraceGraph_ELBO give the same value and gradient; one HIP evaluation serves both.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .poutine import ScaledFn
+
+
+class _ELBO:
+    def __init__(self, num_particles: int = 1, max_plate_nesting: int = float("inf"), vectorize_particles: bool = False,
+                 **kwargs):
+        if int(num_particles) != 1:
+            raise NotImplementedError("num_particles > 1 (SURVEY.md 8(f) item 4)")
+        self.num_particles = 1
+        self.max_plate_nesting = max_plate_nesting
+        self.vectorize_particles = vectorize_particles
+
+
+class Trace_ELBO(_ELBO):  # noqa: N801
+    pass
+
+
+class TraceGraph_ELBO(_ELBO):  # noqa: N801
+    pass
+
+
+class RenyiELBO(_ELBO):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("RenyiELBO is a different estimator (num_particles > 1), outside this build's hot path")
+
+
+OBJECTIVE_DICT = {"elbo": Trace_ELBO, "graphelbo": TraceGraph_ELBO, "renyielbo": RenyiELBO}
+
+
+def _unwrap(fn):
+    scale = 1.0
+    while isinstance(fn, ScaledFn):
+        scale *= fn.scale
+        fn = fn.fn
+    owner = getattr(fn, "__self__", None)
+    if owner is None or not hasattr(owner, "_engine_for"):
+        raise TypeError("SVI needs model=<gdrf_amd model>.model and guide=<the same model>.guide "
+                        "(optionally wrapped in gdrf_amd.poutine.scale)")
+    return owner, scale
+
+
+class SVI:
+    def __init__(self, model, guide, optim, loss, **kwargs):
+        m_owner, m_scale = _unwrap(model)
+        g_owner, g_scale = _unwrap(guide)
+        if m_owner is not g_owner:
+            raise ValueError("model and guide must be methods of the same gdrf_amd model")
+        if abs(m_scale - g_scale) > 1e-15 * max(m_scale, g_scale):
+            raise ValueError("model and guide carry different poutine.scale factors")
+        if not isinstance(loss, _ELBO):
+            raise TypeError("loss must be gdrf_amd.infer.Trace_ELBO or TraceGraph_ELBO")
+        self.gdrf = m_owner
+        self.scale = m_scale
+        self.optim = optim
+        self.loss = loss
+        self.row_offset = 0            # global index of this rank's first observation (Philox key)
+        self.steps_taken = 0
+
+    def step(self, *args, xs=None, ws=None, subsample=False, eps: Optional[torch.Tensor] = None) -> float:
+        """One SVI step on (xs, ws) (this rank's shard when torch.distributed is initialised).
+        ``eps`` (K, n) injects the N(0,1) draw of the guide's mu site for seed-for-seed parity."""
+        if args:
+            xs = args[0]
+            ws = args[1] if len(args) > 1 else ws
+        model = self.gdrf
+        xs_s, ws_d = model._prepare_inputs(xs, ws)
+        eng = model._engine_for(xs_s.shape[0])
+        self.optim._bind(eng)
+        n = xs_s.shape[0]
+        if eps is None:
+            eps = eng.fill_eps(model.rng_seed, self.steps_taken, self.row_offset, n)
+        else:
+            eps = torch.as_tensor(eps).to(device=eng.device, dtype=eng.dtype).contiguous()
+        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale)
+        self.optim._step()
+        out = eng.read_out()
+        self.steps_taken += 1
+        self.last = out
+        return float(out["loss"])
+
+    def evaluate_loss(self, *args, xs=None, ws=None, subsample=False, eps=None) -> float:
+        if args:
+            xs = args[0]
+            ws = args[1] if len(args) > 1 else ws
+        model = self.gdrf
+        xs_s, ws_d = model._prepare_inputs(xs, ws)
+        eng = model._engine_for(xs_s.shape[0])
+        n = xs_s.shape[0]
+        if eps is None:
+            eps = eng.fill_eps(model.rng_seed, self.steps_taken, self.row_offset, n)
+        else:
+            eps = torch.as_tensor(eps).to(device=eng.device, dtype=eng.dtype).contiguous()
+        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale)
+        return float(eng.read_out()["loss"])

@@ -1,0 +1,323 @@
+"""``SparseMultinomialGDRF`` with the reference's constructor, predictive and bookkeeping surface
+(gdrf/models/sparse_gdrf.py:16-123,161-190,321-409; gdrf/models/abstract_gdrf.py:26-139;
+gdrf/models/topic_model.py:148-202), evaluated by hand-written HIP kernels.
+
+Host side keeps only shapes, bounds and the flat parameter vector (a PyTorch-ROCm tensor used as
+storage); all arithmetic of model/guide/log_topic_probs runs in libgdrf_hip.  ``model`` and
+``guide`` are handles for :class:`gdrf_amd.infer.SVI` exactly as ``pyro.infer.SVI(model=model.model,
+guide=model.guide, ...)`` takes them (gdrf/train_script.py:365-371).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Callable, Dict, List, Optional, Tuple, Union
+
+import torch
+
+from ..engine import Engine
+from ..kernels import Kernel
+
+_PARAM_KEYS = {  # state_dict names follow pyro's "<name>_unconstrained" convention
+    "log_lengthscale": "_kernel.lengthscale_unconstrained",
+    "log_variance": "_kernel.variance_unconstrained",
+    "log_noise": "noise_unconstrained",
+    "u_loc": "u_loc_unconstrained",
+    "phi_unc": "_word_topic_matrix_map_unconstrained",
+    "u_scale_tril_unc": "u_scale_tril_unconstrained",
+}
+
+
+def validate_dirichlet_param(b: torch.Tensor, K: int, V: int) -> torch.Tensor:
+    """gdrf/models/utils.py:6-24."""
+    b = torch.as_tensor(b, dtype=torch.float64)
+    assert (b <= 0).sum().item() == 0, "b must be positive"
+    if b.dim() == 0:
+        return torch.ones(K, V, dtype=torch.float64) * b
+    if b.dim() == 1:
+        if b.shape[0] == K:
+            return b.repeat(V, 1).T.contiguous()
+        if b.shape[0] == V:
+            return b.repeat(K, 1)
+        raise ValueError("parameter b must have length K or V if 1D")
+    if b.dim() == 2:
+        assert tuple(b.shape) == (K, V), "b should be KxV if 2D"
+        return b
+    raise ValueError("invalid b parameter- you passed %s" % (b,))
+
+
+class ModelSnapshot:
+    """What ``deepcopy(model).half()`` yields for checkpoints (gdrf/train_script.py:490-506):
+    a detached copy of the parameters that supports ``.half()/.float()/.state_dict()``."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], meta: dict):
+        self._state = state
+        self.meta = meta
+
+    def half(self):
+        return ModelSnapshot({k: v.half() for k, v in self._state.items()}, self.meta)
+
+    def float(self):
+        return ModelSnapshot({k: v.float() for k, v in self._state.items()}, self.meta)
+
+    def state_dict(self):
+        return dict(self._state)
+
+    def parameters(self):
+        return list(self._state.values())
+
+
+class SparseMultinomialGDRF:
+    def __init__(
+        self,
+        num_observation_categories: int,
+        num_topic_categories: int,
+        world: List[Tuple[float, float]],
+        kernel: Kernel,
+        dirichlet_param: Union[float, torch.Tensor],
+        n_points: Union[int, List[int]],
+        fixed_inducing_points: bool = False,
+        inducing_init: str = "random",
+        mean_function: Callable = None,
+        link_function: Callable = None,
+        noise: Optional[float] = None,
+        device: str = "cuda:0",
+        whiten: bool = True,
+        jitter: float = 1e-8,
+        maxjitter: int = 5,
+        randomize_wt_matrix: bool = False,
+        randomize_metric=None,
+        randomize_iters: int = 100,
+        dtype: torch.dtype = torch.float32,
+        inducing_points: Optional[torch.Tensor] = None,
+        seed: Optional[int] = None,
+        **kwargs,
+    ):
+        if mean_function is not None or link_function is not None:
+            raise NotImplementedError("custom mean_function / link_function: the HIP path fuses zero_mean and the softmax link "
+                                      "(gdrf/models/abstract_gdrf.py:17-22)")
+        if not whiten:
+            raise NotImplementedError("whiten=False (SURVEY.md 8(f) item 4)")
+        if not fixed_inducing_points:
+            raise NotImplementedError("learnable inducing points (fixed_inducing_points=False) are SURVEY.md 8(f) item 4; "
+                                      "train() defaults to fixed_inducing_points=True (gdrf/train_script.py:115)")
+        if randomize_metric is not None:
+            raise NotImplementedError("randomize_metric")
+        if not isinstance(kernel, Kernel):
+            raise TypeError("kernel must be a gdrf_amd.kernels.RBF or Matern52")
+        self._V = int(num_observation_categories)
+        self._K = int(num_topic_categories)
+        self._world = [(float(a), float(b)) for a, b in world]
+        self._n_dims = len(self._world)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self._kernel = kernel
+        if kernel.input_dim != self._n_dims:
+            raise ValueError("kernel.input_dim does not match the world's dimensionality")
+        self._lower = torch.tensor([b[0] for b in self._world], dtype=torch.float64)
+        self._upper = torch.tensor([b[1] for b in self._world], dtype=torch.float64)
+        self._delta = self._upper - self._lower
+        self._jitter, self._maxjitter, self._whiten = float(jitter), int(maxjitter), True
+        self._fixed_inducing_points = True
+        if isinstance(dirichlet_param, float):
+            dirichlet_param = torch.tensor(dirichlet_param)
+        self._dirichlet_param = validate_dirichlet_param(dirichlet_param, self._K, self._V)
+        self._n_points = [n_points for _ in self._world] if isinstance(n_points, int) else list(n_points)
+        self.rng_seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
+        gen = torch.Generator().manual_seed(self.rng_seed)
+        # ---- inducing points: sparse_gdrf.py:54-77
+        if inducing_points is not None:
+            Z = torch.as_tensor(inducing_points, dtype=torch.float64)
+        else:
+            if inducing_init == "random":
+                pts = [torch.sort(torch.rand(self._n_points[i], generator=gen, dtype=torch.float64))[0] * self._delta[i]
+                       + self._lower[i] for i in range(self._n_dims)]
+            elif inducing_init == "grid":
+                pts = [torch.arange(b[0], b[1] + (b[1] - b[0]) / (n - 1) - 1e-10, (b[1] - b[0]) / (n - 1), dtype=torch.float64)
+                       for b, n in zip(self._world, self._n_points)]
+            else:
+                raise ValueError(f"inducing_init argument {inducing_init} not valid. Only 'random' and 'grid' are "
+                                 "currently supported")
+            Z = torch.stack([x.flatten() for x in torch.meshgrid(*pts, indexing="ij")]).T
+            Z = (Z - self._lower) / self._delta
+        self._inducing_points = Z.to(dtype).contiguous()
+        self.M, self.D = int(Z.shape[0]), int(Z.shape[1])
+        self.latent_shape = torch.Size([self._K])
+        self._engine: Optional[Engine] = None
+        self._init_noise = 1.0 if noise is None else float(noise)
+        self._randomize_wt = bool(randomize_wt_matrix)
+        self._gen = gen
+        xs = kwargs.get("xs")
+        self._engine_for(int(xs.shape[0]) if xs is not None else 1)
+
+    # ------------------------------------------------------------------ engine / parameters
+    def _engine_for(self, n: int) -> Engine:
+        e = self._engine
+        if e is not None and n <= e.n_cap:
+            return e
+        new = Engine(n, self.M, self._K, self._V, self.D, dtype=self.dtype, kernel=self._kernel.name, device=self.device,
+                     jitter=self._jitter, maxjitter=self._maxjitter)
+        new.set_inducing_points(self._inducing_points)
+        new.set_dirichlet(self._dirichlet_param)
+        if e is None:
+            self._init_params(new)
+        else:                                   # grow the workspaces, keep parameters and optimizer state
+            new.params.copy_(e.params); new.exp_avg.copy_(e.exp_avg); new.exp_avg_sq.copy_(e.exp_avg_sq)
+            new.opt_step = e.opt_step
+        self._engine = new
+        self._inducing_points = new.Z
+        return new
+
+    def _init_params(self, eng: Engine):
+        """sparse_gdrf.py:96-122 and abstract_gdrf.py:57-84."""
+        with torch.no_grad():
+            eng.view("log_lengthscale").fill_(float(self._kernel.lengthscale.log()))
+            eng.view("log_variance").fill_(float(self._kernel.variance.log()))
+            eng.view("log_noise").fill_(float(torch.tensor(self._init_noise, dtype=torch.float64).log()))
+            eng.view("u_loc").zero_()
+            ret = torch.softmax(self._dirichlet_param, dim=-2)           # over K (abstract_gdrf.py:68-69)
+            if self._randomize_wt:
+                ret = torch.softmax(torch.randn(ret.shape, generator=self._gen, dtype=torch.float64), dim=-2)
+            eng.view("phi_unc").copy_(ret.log().to(eng.dtype))            # simplex transform inverse
+            eng.factorize()                                               # u_scale_tril = jittercholesky(kernel(Z)) x K
+            L = eng.workspace("L")
+            unc = L.tril(-1) + torch.diag(L.diagonal().log())             # lower_cholesky transform inverse
+            eng.view("u_scale_tril_unc").copy_(unc.unsqueeze(0).expand(self._K, -1, -1))
+
+    @property
+    def K(self):
+        return self._K
+
+    @property
+    def V(self):
+        return self._V
+
+    @property
+    def dims(self):
+        return self._n_dims
+
+    # ------------------------------------------------------------------ scaling (topic_model.py:168-198)
+    def scale(self, input: torch.Tensor) -> torch.Tensor:
+        return (input - self._lower.to(input)) / self._delta.to(input)
+
+    def _check_bounds(self, input: torch.Tensor, epsilon: float = 1e-8) -> bool:
+        lo, hi = self._lower.to(input), self._upper.to(input)
+        return input.shape[-1] == self._n_dims and bool(((input - lo > -epsilon) & (input - hi < epsilon)).all())
+
+    def _prepare_inputs(self, xs, ws=None):
+        """@scale_decorator semantics: bounds assertion then the affine map to the unit cube (identity for the
+        world train() builds, train_script.py:261-271).  The guide's second scaling (quirk Q3) is NOT reproduced."""
+        xs = torch.as_tensor(xs)
+        if xs.dim() == 1:
+            xs = xs.unsqueeze(-1)
+        xs = xs.to(self.device)
+        assert self._check_bounds(xs), "inputs fall outside the model's world bounds"
+        unit = all(a == 0.0 and b == 1.0 for a, b in self._world)
+        xs_s = xs if unit else self.scale(xs)
+        xs_s = xs_s.to(self.dtype).contiguous()
+        ws_d = None
+        if ws is not None:
+            ws_d = torch.as_tensor(ws).to(device=self.device, dtype=torch.int32).contiguous()
+            if ws_d.shape != (xs_s.shape[0], self._V):
+                raise ValueError(f"ws must have shape ({xs_s.shape[0]}, {self._V})")
+        return xs_s, ws_d
+
+    # ------------------------------------------------------------------ SVI handles
+    def model(self, xs, ws, subsample=False):
+        raise NotImplementedError("SparseMultinomialGDRF.model is evaluated through gdrf_amd.infer.SVI (fused with the guide "
+                                  "in one HIP forward/backward); it is not a traceable Pyro program")
+
+    def guide(self, xs, ws, subsample=False):
+        raise NotImplementedError("SparseMultinomialGDRF.guide is evaluated through gdrf_amd.infer.SVI")
+
+    def train(self, mode: bool = True):
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ predictive path
+    def log_topic_probs(self, xs) -> torch.Tensor:
+        """f_loc (K, N): sparse_gdrf.py:161-186 (mean only; the discarded variance is never computed)."""
+        xs_s, _ = self._prepare_inputs(xs)
+        return self._engine_for(1).predict(xs_s, 0)
+
+    def topic_probs(self, xs) -> torch.Tensor:
+        xs_s, _ = self._prepare_inputs(xs)
+        return self._engine_for(1).predict(xs_s, 1)
+
+    def word_probs(self, xs) -> torch.Tensor:
+        xs_s, _ = self._prepare_inputs(xs)
+        return self._engine_for(1).predict(xs_s, 2)
+
+    def ml_topics(self, xs):
+        return torch.argmax(self.log_topic_probs(xs), dim=-2)
+
+    def ml_words(self, xs):
+        return torch.argmax(self.word_probs(xs), dim=-2)
+
+    def perplexity(self, x, w) -> torch.Tensor:
+        """exp(-sum w log p / sum w): abstract_gdrf.py:137-139, as a 0-d tensor (train_script.py:469-472 calls .item())."""
+        xs_s, ws_d = self._prepare_inputs(x, w)
+        s = self._engine_for(1).predict(xs_s, 3, ws_d)
+        return torch.exp(-s[0] / s[1])
+
+    @property
+    def word_topic_matrix(self) -> torch.Tensor:
+        return torch.softmax(self._engine.view("phi_unc"), dim=-1)
+
+    @property
+    def kernel_lengthscale(self):
+        return self._engine.view("log_lengthscale").exp().detach().cpu().numpy()
+
+    @property
+    def kernel_variance(self):
+        return self._engine.view("log_variance").exp().detach().cpu().numpy()
+
+    @property
+    def noise(self):
+        return self._engine.view("log_noise").exp()
+
+    @property
+    def u_loc(self):
+        return self._engine.view("u_loc")
+
+    @property
+    def u_scale_tril(self):
+        u = self._engine.view("u_scale_tril_unc")
+        return u.tril(-1) + torch.diag_embed(u.diagonal(dim1=-2, dim2=-1).exp())
+
+    def artifacts(self, xs, ws, all: bool = False):
+        return {"kernel variance": self.kernel_variance, "kernel lengthscale": self.kernel_lengthscale}
+
+    # ------------------------------------------------------------------ state (train_script.py:338-363,490-506)
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        v = self._engine.named_views()
+        return {_PARAM_KEYS[n]: v[n].detach().clone() for n in self._engine.PARAM_NAMES}
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True):
+        v = self._engine.named_views()
+        missing = []
+        for n in self._engine.PARAM_NAMES:
+            key = _PARAM_KEYS[n]
+            if key not in state:
+                missing.append(key)
+                continue
+            t = torch.as_tensor(state[key])
+            if tuple(t.shape) != tuple(v[n].shape):
+                if strict:
+                    raise RuntimeError(f"size mismatch for {key}: {tuple(t.shape)} vs {tuple(v[n].shape)}")
+                continue
+            v[n].copy_(t.to(v[n]))
+        if strict and missing:
+            raise RuntimeError(f"missing keys: {missing}")
+        return missing
+
+    def parameters(self):
+        return list(self._engine.named_views().values())
+
+    def float(self):
+        return self
+
+    def __deepcopy__(self, memo):
+        meta = dict(K=self._K, V=self._V, M=self.M, D=self.D, world=list(self._world), kernel=repr(self._kernel))
+        return ModelSnapshot(self.state_dict(), meta)
