@@ -58,6 +58,29 @@ def lattice_shape(n):
     return n // w, w
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use (cgroup quota / affinity), not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return min(n, int(os.environ.get("GDRF_BENCH_CPU_THREADS", 16)))
+
+
 def cpu_baseline(args, M_points):
     """Reference-shaped oracle (2x conditional, materialised W.S, autograd, per-parameter Adam), fp32,
     all host threads, on a bounded sample of the same workload; extrapolated linearly in N."""
@@ -66,7 +89,7 @@ def cpu_baseline(args, M_points):
     ns = args.cpu_baseline_n
     W, H = lattice_shape(ns)
     xs, ws, _ = synth_circles(W, H, args.vocab, args.topics, seed=args.seed)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     m = RefShapedGDRF(xs, ws, kind=args.kernel, K=args.topics, n_points=tuple(args.n_points), dtype=torch.float32,
                       jitter=args.jitter, maxjitter=15, optimizer="adam", lr=1e-3)
@@ -173,7 +196,7 @@ def main():
         ms = {k: (v["ms"] / v["count"] if v["count"] else 0.0) for k, v in timing.items()}
         per_step = {k: v["ms"] / args.steps for k, v in timing.items()}
         flops = {  # useful flops per launch (triangular/symmetric halves skipped, nothing counted twice)
-            "fwd_w": 1.0 * n_loc * M * M, "fwd_t": 1.0 * n_loc * M * M * K, "bwd_wbar": 2.0 * n_loc * M * M * K,
+            "fwd_w": 1.0 * n_loc * M * M, "loc": 2.0 * n_loc * M * K, "fwd_t": 1.0 * n_loc * M * M * K, "bwd_wbar": 2.0 * n_loc * M * M * K,
             "bwd_knm": 1.0 * n_loc * M * M, "tn_sym": 1.0 * n_loc * M * M * K, "tn_gt": 2.0 * n_loc * M * M,
         }
         dom = max(flops, key=lambda k: per_step[k])

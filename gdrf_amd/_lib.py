@@ -48,6 +48,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: libgdrf_hip.so needs libamdhip64.so.7, and the process must end up with ONE HIP
+    # runtime (the one PyTorch-ROCm bundles and has already loaded), not a second copy from /opt/rocm.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GdrfHipError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run "

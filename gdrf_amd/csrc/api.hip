@@ -40,7 +40,7 @@ struct gdrf_ctx {
   int nsplit_cap;
   // M x M (ld Mp)
   void *Kuu, *Lw, *L, *LT, *Linv, *LinvT, *Dinv, *S, *ST, *Bm, *t0, *t1, *t2, *Sbar;
-  void *phi, *Cf;
+  void *phi, *Cf, *Upad, *qpart;
   // N side
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
   // partials
@@ -97,14 +97,21 @@ int gdrf_red_layout(const gdrf_ctx* c, int64_t out[6]) {
   return 0;
 }
 
+// number of row splits of the TN kernels: fill the chip's resident-workgroup slots (256 CUs x 3) with as
+// little last-round idling as possible, keep >= 8 chunks per split, cap the slab memory
 static int tn_nsplit(const gdrf_ctx* c, int64_t n, int BR) {
   const int tiles = c->K * c->nt * (c->nt + 1) / 2;
-  int ns = (1024 + tiles - 1) / tiles;
-  if (ns > 32) ns = 32;
-  const int64_t maxs = (n + 8 * BR - 1) / (8 * BR);      // at least 8 chunks per split
-  if (ns > maxs) ns = (int)maxs;
-  if (ns < 1) ns = 1;
-  return ns;
+  const double slots = 256.0 * 3.0;
+  int64_t maxs = (n + 8 * BR - 1) / (8 * BR);
+  if (maxs > 64) maxs = 64;
+  if (maxs < 1) maxs = 1;
+  int best = 1; double best_eff = 0;
+  for (int ns = 1; ns <= maxs; ++ns) {
+    const double rounds = tiles * (double)ns / slots;
+    const double eff = rounds / std::ceil(rounds);
+    if (eff > best_eff + 1e-9 || (eff > best_eff - 0.02 && rounds >= 2.0 && tiles * (double)best / slots < 2.0)) { best_eff = eff; best = ns; }
+  }
+  return best;
 }
 
 int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id) {
@@ -135,6 +142,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
   AL(c->t0, mm) AL(c->t1, mm) AL(c->t2, mm)
   AL(c->phi, (size_t)K * V * c->esz) AL(c->Cf, (size_t)K * M * c->esz)
+  AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)c->nt * c->ldk * c->esz)
   AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
   AL(c->q, (size_t)c->ldk * c->esz) AL(c->asum, (size_t)c->ldk * c->esz)
   AL(c->loc, (size_t)K * c->ldk * c->esz) AL(c->tt, (size_t)K * c->ldk * c->esz) AL(c->vbar, (size_t)K * c->ldk * c->esz)
@@ -146,7 +154,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   c->erows_grid_cap = 1024;
   AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
   const int64_t rtiles = (n_cap + GDRF_TILE - 1) / GDRF_TILE;
-  c->dpart_len = std::max<int64_t>(rtiles * c->nt * 2, 8192);
+  c->dpart_len = std::max<int64_t>((rtiles * c->nt + 16) * 2, 8192);
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
@@ -241,7 +249,7 @@ template <typename T> struct Impl {
 
   static int mm_nt(gdrf_ctx* c, const T* A, int64_t abs_, const T* Bt, int64_t bbs, T* Cm, int64_t cbs, T alpha, int batch,
                    hipStream_t s) {
-    MMProb<T> p{A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
+    MMProb<T> p{{}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
     dim3 grid(c->nt * c->nt, batch);
     hipLaunchKernelGGL((gemm_nt_kernel<T, MMProb<T>>), grid, dim3(256), C::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");
@@ -269,11 +277,11 @@ template <typename T> struct Impl {
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     ScopedTimer tm(c, 1, s);
     const int VE = Vec16<T>::N;
-    const int64_t total = n * ((c->M + VE - 1) / VE);
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int vpr = (c->M + VE - 1) / VE, rpp = vpr <= 256 ? 256 / vpr : 1;
+    int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
+    if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(knm_kernel<T>, dim3((unsigned)blocks), dim3(256), (size_t)c->M * c->D * sizeof(T), s, X, n, Z, c->M, c->D,
+    hipLaunchKernelGGL(knm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D,
                        c->kind, c->hyp, out, ldo);
     LAUNCHCHK("knm");
     return 0;
@@ -292,6 +300,7 @@ template <typename T> struct Impl {
       dim3 g3((Mp + 255) / 256, Mp, K);
       hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
       hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
+      hipLaunchKernelGGL(build_upad_kernel<T>, dim3((Mp + 255) / 256, GDRF_TILE), dim3(256), 0, s, U, K, M, Mp, P(c->Upad));
       if ((rc = mm_nt(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
     }
 
@@ -299,19 +308,22 @@ template <typename T> struct Impl {
     // (1) W = Knm Linv^T
     {
       ScopedTimer tm(c, 3, s);
-      FwdWProb<T> p{X, n, Z, M, Mp, c->D, c->kind, c->hyp, P(c->Linv), P(c->W)};
-      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdWProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), C::LDS_BYTES, s, p);
+      FwdWProb<T> p{{}, X, n, Z, M, Mp, c->D, c->kind, c->hyp, P(c->Linv), P(c->W), P(c->qpart), ldk};
+      const size_t lds = C::LDS_BYTES + (size_t)Mp * c->D * sizeof(T);
+      if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FwdWProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdWProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), lds, s, p);
     }
-    // q, loc
+    // loc = W U^T
     {
       ScopedTimer tm(c, 4, s);
-      int64_t blocks = (n + 3) / 4; if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(rowstats_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, P(c->W), n, M, Mp, K, U, P(c->q), P(c->loc), ldk);
+      LocProb<T> p{{}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
+      hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, s, p);
     }
     // (2) tt_kn = ||S_k^T w_n||^2
     {
       ScopedTimer tm(c, 5, s);
-      FwdTProb<T> p{P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
+      FwdTProb<T> p{{}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
     }
     LAUNCHCHK("forward");
@@ -327,8 +339,8 @@ template <typename T> struct Impl {
         HIPCHK(hipFuncSetAttribute((const void*)elbo_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t nblk = (n + RB - 1) / RB;
       egrid = (int)std::min<int64_t>(nblk, c->erows_grid_cap);
-      hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->q), P(c->loc), P(c->tt), eps, ldk, n,
-                         ws, P(c->phi), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+      hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), c->nt, P(c->loc), P(c->tt), eps,
+                         ldk, n, ws, P(c->phi), P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
       LAUNCHCHK("elbo_rows");
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
@@ -337,13 +349,16 @@ template <typename T> struct Impl {
     // (3) Wbar
     {
       ScopedTimer tm(c, 7, s);
-      BwdWbarProb<T> p{P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), C::LDS_BYTES, s, p);
+      BwdWbarProb<T> p{{}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
+      const size_t lds = C::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(T);
+      if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)round_up(rtiles * c->nt, 8)), dim3(256), lds, s, p);
     }
     // (4) kernel hyper-parameter partials through Knm
     {
       ScopedTimer tm(c, 8, s);
-      BwdKnmProb<T> p{P(c->Wbar), n, M, Mp, c->D, c->kind, P(c->LinvT), X, Z, c->hyp, c->dpart};
+      BwdKnmProb<T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, P(c->LinvT), X, Z, c->hyp, c->dpart};
       const int64_t nb = rtiles * c->nt;
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
       hipLaunchKernelGGL((gemm_nt_kernel<T, BwdKnmProb<T>>), dim3((unsigned)nb), dim3(256), C::LDS_BYTES, s, p);
@@ -353,17 +368,17 @@ template <typename T> struct Impl {
     // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
     {
       const int BR = TNCfg<T>::BR;
-      const int ns = tn_nsplit(c, n, BR);
+      const int ns = std::min(tn_nsplit(c, n, BR), c->nsplit_cap);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
-      TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K};
+      TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K, ns};
       { ScopedTimer tm(c, 9, s);
-        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * (c->nt + 1) / 2, K, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, a); }
+        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * (c->nt + 1) / 2 * K * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, a); }
       { ScopedTimer tm(c, 11, s);
         dim3 gr((Mp + 255) / 256, Mp, K);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2)); }
-      TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, P(c->slab), 1};
+      TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, P(c->slab), 1, ns};
       { ScopedTimer tm(c, 10, s);
-        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(c->nt * c->nt, 1, ns), dim3(256), TNCfg<T>::LDS_BYTES, s, b); }
+        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, b); }
       { ScopedTimer tm(c, 11, s);
         dim3 gr1((Mp + 255) / 256, Mp, 1);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, s, P(c->slab), ns, 1, Mp, 0, redT + roff(c, 3)); }

@@ -3,14 +3,23 @@
 // 256-thread workgroup (4 waves as 2x2, each wave 4x4 MFMA tiles), 128 bytes of k per row
 // per chunk staged through LDS with a register prefetch of the next chunk.
 //
-// The problem object P supplies the operands and the epilogue:
-//   int  col_tiles()                       number of 128-wide column tiles
-//   bool loop_cols()                       true: one workgroup walks every column tile of its row tile
-//   void krange(m0, n0, bz, kb, ke)        reduction range [kb, ke), multiples of BK (triangular skipping)
-//   void prepA(ctx, m0, bz) / V loadA(ctx, i, k, bz)   i = 0..VPT-1 selects the thread's i-th staged row
-//   V    loadB(n0, i, k, bz)
-//   void tile_done(acc, m0, n0, bz, ectx)  per output tile
-//   void finish(m0, bz, ectx, smem)        once per workgroup (after all its column tiles)
+// The reduction is a sequence of chunks c = 0 .. nchunks-1.  Chunk c uses A columns
+// [kb + (c / R) * BK, +BK) and B "repeat" r = c % R of the same columns, where R = a_reuse():
+// with R > 1 one staged A chunk serves R consecutive B chunks (each with its own per-row scale
+// of A, read from an LDS table) -- the topic loop of the Wbar contraction, which would otherwise
+// re-stream the W tile from HBM once per topic.
+//
+// The problem object P supplies operands and epilogue:
+//   static constexpr bool SCALE_A         per-(repeat,row) scale of the A fragments from LDS
+//   int  col_tiles(); bool loop_cols();   loop_cols: one workgroup walks every column tile of its row tile
+//   int  a_reuse()
+//   int  extra_lds_bytes()                problem-owned LDS behind the two staging tiles
+//   void krange(m0, n0, bz, kb, ke)       A-column range [kb, ke), multiples of BK (triangular skipping)
+//   void prepA(actx, m0, bz, extra) ; V loadA(actx, i, k, bz)     i = 0..VPT-1: the thread's i-th staged row
+//   V    loadB(n0, i, k, rep, bz)
+//   void prepE(ectx, m0, bz)
+//   void tile_done(acc, m0, n0, bz, ectx, wr, wc, lane)
+//   void finish(m0, bz, ectx, smem, wr, wc, lane)     once per workgroup
 #pragma once
 #include "common.h"
 
@@ -39,21 +48,24 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = As + GDRF_TILE * C::LDK;
+  char* extra = smem + C::LDS_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   const int nct = p.col_tiles();
   const bool loopc = p.loop_cols();
-  const int64_t rtile = loopc ? (int64_t)blockIdx.x : (int64_t)blockIdx.x / nct;
-  const int ct_first = loopc ? 0 : (int)(blockIdx.x % nct);
+  int64_t rtile; int ct_first;
+  p.map_block(blockIdx.x, nct, loopc, rtile, ct_first);
   const int ct_last = loopc ? nct : ct_first + 1;
   const int64_t m0 = rtile * GDRF_TILE;
   const int bz = blockIdx.y;
+  const int R = p.a_reuse();
 
   typename P::ACtx actx;
-  p.prepA(actx, m0, bz);
+  p.prepA(actx, m0, bz, extra);
   typename P::ECtx ectx;
   p.prepE(ectx, m0, bz);
+  const T* scaleS = reinterpret_cast<const T*>(extra);     // [R][128] when SCALE_A
 
   const int srow_k = nt_stage_k<T>();
   for (int ct = ct_first; ct < ct_last; ++ct) {
@@ -65,23 +77,36 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
       for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
     int kb, ke;
     p.krange(m0, n0, bz, kb, ke);
+    const int nchunks = (ke > kb) ? ((ke - kb) / C::BK) * R : 0;
     V ra[C::VPT], rb[C::VPT];
-    if (kb < ke) {
+    if (nchunks > 0) {
 #pragma unroll
-      for (int i = 0; i < C::VPT; ++i) { ra[i] = p.loadA(actx, i, kb + srow_k, bz); rb[i] = p.loadB(n0, i, kb + srow_k, bz); }
+      for (int i = 0; i < C::VPT; ++i) { ra[i] = p.loadA(actx, i, kb + srow_k, bz); rb[i] = p.loadB(n0, i, kb + srow_k, 0, bz); }
     }
-    for (int k = kb; k < ke; k += C::BK) {
+    int rep = 0, kA = kb;
+    for (int c = 0; c < nchunks; ++c) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < C::VPT; ++i) {
         const int r = nt_stage_row<T>(i);
-        *reinterpret_cast<V*>(&As[r * C::LDK + srow_k]) = ra[i];
+        if (rep == 0) *reinterpret_cast<V*>(&As[r * C::LDK + srow_k]) = ra[i];
         *reinterpret_cast<V*>(&Bs[r * C::LDK + srow_k]) = rb[i];
       }
       __syncthreads();
-      if (k + C::BK < ke) {
+      // prefetch the next chunk's operands into registers while this one is multiplied
+      int nrep = rep + 1, nkA = kA;
+      if (nrep == R) { nrep = 0; nkA = kA + C::BK; }
+      if (c + 1 < nchunks) {
 #pragma unroll
-        for (int i = 0; i < C::VPT; ++i) { ra[i] = p.loadA(actx, i, k + C::BK + srow_k, bz); rb[i] = p.loadB(n0, i, k + C::BK + srow_k, bz); }
+        for (int i = 0; i < C::VPT; ++i) {
+          if (nrep == 0) ra[i] = p.loadA(actx, i, nkA + srow_k, bz);
+          rb[i] = p.loadB(n0, i, nkA + srow_k, nrep, bz);
+        }
+      }
+      T sc[4];
+      if (P::SCALE_A) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) sc[t4] = scaleS[rep * GDRF_TILE + wr * 64 + t4 * 16 + lr];
       }
       // fragments: lane (lr, lg) owns k indices lg*KG .. lg*KG+KG-1 of this chunk for row/col lr
       const T* pa = &As[(wr * 64 + lr) * C::LDK + lg * C::KG];
@@ -93,6 +118,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
         for (int t4 = 0; t4 < 4; ++t4) {
           fa[t4] = *reinterpret_cast<const V*>(pa + t4 * 16 * C::LDK + v * C::VE);
           fb[t4] = *reinterpret_cast<const V*>(pb + t4 * 16 * C::LDK + v * C::VE);
+          if (P::SCALE_A) {
+#pragma unroll
+            for (int e = 0; e < C::VE; ++e) fa[t4][e] *= sc[t4];
+          }
         }
 #pragma unroll
         for (int e = 0; e < C::VE; ++e)
@@ -101,6 +130,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
       }
+      rep = nrep; kA = nkA;
     }
     p.tile_done(acc, m0, n0, bz, ectx, wr, wc, lane);
   }
@@ -112,5 +142,49 @@ template <typename T> __device__ __forceinline__ int nt_acc_row(int wr, int a, i
   return wr * 64 + a * 16 + Mfma<T>::crow(lane, r);
 }
 __device__ __forceinline__ int nt_acc_col(int wc, int b, int lane) { return wc * 64 + b * 16 + (lane & 15); }
+
+// default block -> (row tile, column tile) map: column tile fastest
+struct NTDefaultMap {
+  __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
+    if (loopc) { rtile = bid; ct = 0; } else { rtile = bid / nct; ct = (int)(bid % nct); }
+  }
+};
+// XCD-aware map (speed only: blocks b and b+8 are observed to share an XCD, MI355X_MICROARCH.md): every
+// XCD works on ONE column tile at a time so that tile's B panels stay resident in its 4 MiB L2, and
+// the row tiles are dealt round-robin.  Bijective whenever nct divides 8; falls back otherwise.
+struct NTXcdMap {
+  __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
+    if (loopc) { rtile = bid; ct = 0; return; }
+    if (nct > 8 || (8 % nct) != 0 || (gridDim.x % 8u) != 0) { rtile = bid / nct; ct = (int)(bid % nct); return; }
+    const unsigned xcd = bid & 7u, idx = bid >> 3, per = 8u / (unsigned)nct;   // XCDs per column tile
+    ct = (int)(xcd % (unsigned)nct);
+    rtile = (int64_t)idx * per + xcd / (unsigned)nct;
+  }
+};
+
+// row-sum-of-squares epilogue shared by the problems that need it: per-lane partials rs[a][r] over the lane's
+// columns -> 16-lane groups -> the two waves that share the rows -> rsum[128] in LDS
+template <typename T>
+__device__ __forceinline__ void nt_rowsum_finish(T (&rs)[4][4], T* rsum, int wr, int wc, int lane) {
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[a][r] = group16_sum(rs[a][r]);
+  if (wc == 0 && (lane & 15) == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rsum[nt_acc_row<T>(wr, a, lane, r)] = rs[a][r];
+  }
+  __syncthreads();
+  if (wc == 1 && (lane & 15) == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rsum[nt_acc_row<T>(wr, a, lane, r)] += rs[a][r];
+  }
+  __syncthreads();
+}
 
 }  // namespace gdrf

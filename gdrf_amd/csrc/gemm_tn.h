@@ -26,6 +26,7 @@ template <typename T> struct TNArgs {
   int sym;                           // 1: only tiles ti >= tj (blockIdx.x enumerates the lower triangle)
   T* slab;                           // [nsplit][nbatch][ncols][ncols]
   int nbatch;
+  int nsplit;                        // gridDim.x = ntiles * nbatch * nsplit
 };
 
 template <typename T>
@@ -40,13 +41,29 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_tn_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   const int nt = (g.ncols + GDRF_TILE - 1) / GDRF_TILE;
+  const int ntiles = g.sym ? nt * (nt + 1) / 2 : nt * nt;
+  // block -> (tile, batch, split).  With a multiple of 8 splits, split sp runs on the blocks with
+  // blockIdx % 8 == sp % 8 (observed to share an XCD, MI355X_MICROARCH.md): the tiles of one split walk the
+  // same rows of W at the same time, so each XCD's L2 serves one row window to all of them.  Speed only.
+  int tile, b, sp;
+  {
+    const unsigned bid = blockIdx.x;
+    if ((g.nsplit & 7) == 0) {
+      const unsigned xcd = bid & 7u, idx = bid >> 3, per = (unsigned)(ntiles * g.nbatch);
+      const unsigned sl = idx / per, r = idx - sl * per;
+      sp = (int)(sl * 8u + xcd); b = (int)(r / (unsigned)ntiles); tile = (int)(r % (unsigned)ntiles);
+    } else {
+      tile = (int)(bid % (unsigned)ntiles);
+      const unsigned r = bid / (unsigned)ntiles;
+      b = (int)(r % (unsigned)g.nbatch); sp = (int)(r / (unsigned)g.nbatch);
+    }
+  }
   int ti, tj;
   if (g.sym) {
-    int t = blockIdx.x; ti = 0;
+    int t = tile; ti = 0;
     while (t >= ti + 1) { t -= ti + 1; ++ti; }
     tj = t;
-  } else { ti = blockIdx.x / nt; tj = blockIdx.x % nt; }
-  const int b = blockIdx.y, sp = blockIdx.z;
+  } else { ti = tile / nt; tj = tile % nt; }
   const int i0 = ti * GDRF_TILE, j0 = tj * GDRF_TILE;
   const int64_t r0 = (int64_t)sp * g.rows_per_split;
   int64_t r1 = r0 + g.rows_per_split; if (r1 > g.nrows) r1 = g.nrows;
@@ -62,6 +79,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_tn_kernel(
   const int scol = (tid % C::VPR) * C::VE;
   const bool a_ok = (i0 + scol) < g.ncols, b_ok = (j0 + scol) < g.ncols;   // ncols multiple of 32 >= VE
   V ra[C::VPT], rb[C::VPT];
+  T rs[C::VPT];          // row scales travel with the prefetch and are applied at the LDS store, so that the
+                         // loads stay in flight behind the MFMAs instead of being waited for here
   auto gload = [&](int64_t rbase) {
 #pragma unroll
     for (int i = 0; i < C::VPT; ++i) {
@@ -69,16 +88,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_tn_kernel(
       V va, vb;
 #pragma unroll
       for (int e = 0; e < C::VE; ++e) { va[e] = 0; vb[e] = 0; }
+      T s = T(1);
       if (n < r1) {
         if (a_ok) va = *reinterpret_cast<const V*>(g.A + n * g.lda + i0 + scol);
-        if (b_ok) {
-          vb = *reinterpret_cast<const V*>(g.B + n * g.ldb + j0 + scol);
-          if (sc) { const T s = sc[n];
-#pragma unroll
-            for (int e = 0; e < C::VE; ++e) vb[e] *= s; }
-        }
+        if (b_ok) vb = *reinterpret_cast<const V*>(g.B + n * g.ldb + j0 + scol);
+        if (sc) s = sc[n];
       }
-      ra[i] = va; rb[i] = vb;
+      ra[i] = va; rb[i] = vb; rs[i] = s;
     }
   };
   if (r0 < r1) gload(r0);
@@ -87,8 +103,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_tn_kernel(
 #pragma unroll
     for (int i = 0; i < C::VPT; ++i) {
       const int rr = srow + (256 / C::VPR) * i;
+      V vb = rb[i];
+#pragma unroll
+      for (int e = 0; e < C::VE; ++e) vb[e] *= rs[i];
       *reinterpret_cast<V*>(&As[rr * C::LDC + scol]) = ra[i];
-      *reinterpret_cast<V*>(&Bs[rr * C::LDC + scol]) = rb[i];
+      *reinterpret_cast<V*>(&Bs[rr * C::LDC + scol]) = vb;
     }
     __syncthreads();
     if (r + C::BR < r1) gload(r + C::BR);

@@ -203,6 +203,14 @@ __global__ void build_s_kernel(const T* __restrict__ Sunc, int M, int Mp, T* __r
   ST[((int64_t)k * Mp + j) * Mp + i] = v;
 }
 
+// zero-padded copy of u_loc, [128][Mp], the Bt operand of the loc = W U^T product
+template <typename T>
+__global__ void build_upad_kernel(const T* __restrict__ U, int K, int M, int Mp, T* __restrict__ Upad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (j >= Mp) return;
+  Upad[(int64_t)k * Mp + j] = (k < K && j < M) ? U[(int64_t)k * M + j] : T(0);
+}
+
 // row softmax of the word-topic matrix (stack-of-simplex transform)
 template <typename T>
 __global__ void build_phi_kernel(const T* __restrict__ phi_unc, int K, int V, T* __restrict__ phi) {
@@ -216,8 +224,9 @@ __global__ void build_phi_kernel(const T* __restrict__ phi_unc, int K, int V, T*
 }
 
 // ---- plain batched M x M product on the NT core: C[b] = alpha * A[b] * Bt[b]^T ------------------
-template <typename T> struct MMProb {
+template <typename T> struct MMProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = false;
   const T* A; int64_t a_bs;
   const T* Bt; int64_t b_bs;
   T* C; int64_t c_bs;
@@ -225,15 +234,16 @@ template <typename T> struct MMProb {
   struct ACtx { int64_t m0; }; struct ECtx {};
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = Mp; }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const { c.m0 = m0; }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const { c.m0 = m0; }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
   __device__ __forceinline__ V zero() const { V z; for (int e = 0; e < Vec16<T>::N; ++e) z[e] = 0; return z; }
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int bz) const {
     const int64_t r = c.m0 + nt_stage_row<T>(i);
     return (r < Mp) ? *reinterpret_cast<const V*>(A + bz * a_bs + r * Mp + k) : zero();
   }
-  __device__ __forceinline__ V loadB(int n0, int i, int k, int bz) const {
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int, int bz) const {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(Bt + bz * b_bs + (int64_t)c * Mp + k) : zero();
   }

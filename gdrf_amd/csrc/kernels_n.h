@@ -24,57 +24,113 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type vzero()
 // k_nm: the standalone pairwise covariance block K_nm (N x M, row-major).  HBM-write bound:
 // algorithmic bytes = N*M*s + N*D*s + M*D*s.  One 16-byte store per lane, rows contiguous.
 // =====================================================================================
+template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var);
+
 template <typename T>
 __global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64_t N, const T* __restrict__ Z, int M, int D,
                                                   int kind, const Hyper* __restrict__ h, T* __restrict__ out, int64_t ldo) {
   using V = typename Vec16<T>::type;
   constexpr int VE = Vec16<T>::N;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* Zs = reinterpret_cast<T*>(smem);                 // [M][D]
-  for (int e = threadIdx.x; e < M * D; e += blockDim.x) Zs[e] = Z[e];
-  __syncthreads();
   const T var = (T)h->var, ils2 = (T)h->inv_ls2;
-  const int vpr = (M + VE - 1) / VE;                   // vectors per row
-  const int64_t total = N * vpr;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = v / vpr;
-    const int i0 = (int)(v - n * vpr) * VE;
+  const int vpr = (M + VE - 1) / VE;                   // 16-byte vectors per output row
+  const bool aligned = (ldo % VE) == 0;
+  if (vpr <= 256) {
+    // fast path: a thread owns ONE column vector for the whole launch, so its VE inducing points live in
+    // registers; a workgroup pass writes rpp whole rows (contiguous bytes); rows unrolled x4 to keep
+    // several 16-byte stores in flight per lane.  No division inside the loop.
+    const int rpp = 256 / vpr;
+    const int rsub = (int)threadIdx.x / vpr, cv = (int)threadIdx.x % vpr, i0 = cv * VE;
+    if (rsub >= rpp) return;
+    T z[VE][GDRF_DMAX];
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+#pragma unroll
+      for (int d = 0; d < GDRF_DMAX; ++d) z[e][d] = (i0 + e < M && d < D) ? Z[(int64_t)(i0 + e) * D + d] : T(0);
+    const int64_t stride = (int64_t)gridDim.x * rpp;
+    const bool vec_ok = aligned && (i0 + VE <= ldo);
+    for (int64_t row0 = (int64_t)blockIdx.x * rpp + rsub; row0 < N; row0 += 4 * stride) {
+      T x[4][GDRF_DMAX];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t row = row0 + u * stride;
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) x[u][d] = (row < N && d < D) ? X[row * D + d] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t row = row0 + u * stride;
+        if (row >= N) break;
+        V o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          T r2 = 0;
+#pragma unroll
+          for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[u][d] - z[e][d]; r2 += t * t; }
+          o[e] = (i0 + e < M) ? cov_fast<T>(kind, r2 * ils2, var) : T(0);
+        }
+        T* orow = out + row * ldo;
+        if (vec_ok) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0));
+        else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) orow[i0 + e] = o[e];
+      }
+    }
+    return;
+  }
+  // wide rows (M > 256 vectors): one row per workgroup pass, inducing points read through L1
+  for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
     T x[GDRF_DMAX];
 #pragma unroll
-    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[n * D + d] : T(0);
-    V o;
+    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[row * D + d] : T(0);
+    T* orow = out + row * ldo;
+    for (int cv = threadIdx.x; cv < vpr; cv += 256) {
+      const int i0 = cv * VE;
+      V o;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const int i = i0 + e;
-      T r2 = 0;
-      if (i < M) {
+      for (int e = 0; e < VE; ++e) {
+        const int i = i0 + e;
+        T r2 = 0;
+        if (i < M) {
 #pragma unroll
-        for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Zs[i * D + d]; r2 += t * t; }
+          for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Z[(int64_t)i * D + d]; r2 += t * t; }
+        }
+        o[e] = (i < M) ? cov_fast<T>(kind, r2 * ils2, var) : T(0);
       }
-      o[e] = (i < M) ? cov_from_r2<T>(kind, r2 * ils2, var) : T(0);
+      if (aligned && i0 + VE <= ldo) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0));
+      else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) orow[i0 + e] = o[e];
     }
-    if ((ldo % VE) == 0 && i0 + VE <= ldo) __builtin_nontemporal_store(o, reinterpret_cast<V*>(out + n * ldo + i0));
-    else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) out[n * ldo + i0 + e] = o[e];
   }
 }
 
 // =====================================================================================
 // NT-core problems
 // =====================================================================================
-// (1) W = K_nm Linv^T : A generated on the fly, Bt = Linv, triangular k range, store W
-template <typename T> struct FwdWProb {
+// fast exponential for the f32 GEMM operand generators (v_exp_f32); f64 keeps exp()
+template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var) { return cov_from_r2<T>(kind, r2, var); }
+template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2, float var) {
+  if (kind == 0) return var * __expf(-0.5f * r2);
+  const float r = sqrtf(r2 + 1e-12f), a = 2.2360679775f * r;
+  return var * (1.0f + a + (5.0f / 3.0f) * r * r) * __expf(-a);
+}
+
+// (1) W = K_nm Linv^T : A generated on the fly (Z staged in LDS), Bt = Linv, triangular k range; stores W
+//     and the per-column-tile partial of q_n = ||w_n||^2
+template <typename T> struct FwdWProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = false;
   const T* X; int64_t nrows; const T* Z; int M, Mp, D, kind; const Hyper* h;
-  const T* Linv; T* W;
-  struct ACtx { T x[NTCfg<T>::VPT][GDRF_DMAX]; bool ok[NTCfg<T>::VPT]; T var, ils2; };
-  struct ECtx {};
+  const T* Linv; T* W; T* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
+  struct ACtx { T x[NTCfg<T>::VPT][GDRF_DMAX]; bool ok[NTCfg<T>::VPT]; T var, ils2; const T* Zs; };
+  struct ECtx { T rs[4][4]; int ct; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const {
     kb = 0; ke = n0 + GDRF_TILE; if (ke > Mp) ke = Mp;
   }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
-    c.var = (T)h->var; c.ils2 = (T)h->inv_ls2;
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char* extra) const {
+    T* Zs = reinterpret_cast<T*>(extra);                 // [Mp][D], zero rows beyond M
+    for (int e = threadIdx.x; e < Mp * D; e += 256) Zs[e] = (e < M * D) ? Z[e] : T(0);
+    __syncthreads();
+    c.Zs = Zs; c.var = (T)h->var; c.ils2 = (T)h->inv_ls2;
 #pragma unroll
     for (int i = 0; i < NTCfg<T>::VPT; ++i) {
       const int64_t r = m0 + nt_stage_row<T>(i);
@@ -83,29 +139,83 @@ template <typename T> struct FwdWProb {
       for (int d = 0; d < GDRF_DMAX; ++d) c.x[i][d] = (c.ok[i] && d < D) ? X[r * D + d] : T(0);
     }
   }
-  __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
+  __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e.rs[a][r] = 0;
+    e.ct = 0;
+  }
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
     V o;
 #pragma unroll
     for (int e = 0; e < Vec16<T>::N; ++e) {
       const int idx = k + e;
-      T val = 0;
-      if (c.ok[i] && idx < M) {
-        T r2 = 0;
+      T r2 = 0;
 #pragma unroll
-        for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = c.x[i][d] - Z[(int64_t)idx * D + d]; r2 += t * t; }
-        val = cov_from_r2<T>(kind, r2 * c.ils2, c.var);
-      }
-      o[e] = val;
+      for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = c.x[i][d] - c.Zs[idx * D + d]; r2 += t * t; }
+      o[e] = (c.ok[i] && idx < M) ? cov_fast<T>(kind, r2 * c.ils2, c.var) : T(0);
     }
     return o;
   }
-  __device__ __forceinline__ V loadB(int n0, int i, int k, int) const {
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int, int) const {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(Linv + (int64_t)c * Mp + k) : vzero<T>();
   }
   template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx& ec, int wr, int wc, int lane) const {
+    ec.ct = n0 / GDRF_TILE;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          ec.rs[a][r] += acc[a][b][r] * acc[a][b][r];
+          const int n = n0 + nt_acc_col(wc, b, lane);
+          if (m < nrows && n < Mp) W[m * Mp + n] = acc[a][b][r];
+        }
+      }
+  }
+  __device__ __forceinline__ void finish(int64_t m0, int, ECtx& ec, char* smem, int wr, int wc, int lane) const {
+    T* rsum = reinterpret_cast<T*>(smem);
+    nt_rowsum_finish<T>(ec.rs, rsum, wr, wc, lane);
+    if (threadIdx.x < GDRF_TILE) {
+      const int64_t m = m0 + threadIdx.x;
+      if (m < nrows) qpart[(int64_t)ec.ct * ldq + m] = rsum[threadIdx.x];
+    }
+  }
+};
+
+// (1b) loc = W U^T on the matrix cores: Bt = zero-padded u_loc [128][Mp]; stores loc[k][n] for k < K
+template <typename T> struct LocProb : NTDefaultMap {
+  using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = false;
+  const T* W; int64_t nrows; int Mp, K;
+  const T* Upad; T* loc; int64_t ldk;
+  struct ACtx { const T* p[NTCfg<T>::VPT]; };
+  struct ECtx {};
+  __device__ __forceinline__ int col_tiles() const { return 1; }
+  __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ int a_reuse() const { return 1; }
+  __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = Mp; }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const {
+#pragma unroll
+    for (int i = 0; i < NTCfg<T>::VPT; ++i) {
+      const int64_t r = m0 + nt_stage_row<T>(i);
+      c.p[i] = (r < nrows) ? W + r * Mp : nullptr;
+    }
+  }
+  __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+    return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
+  }
+  __device__ __forceinline__ V loadB(int, int i, int k, int, int) const {
+    return *reinterpret_cast<const V*>(Upad + (int64_t)nt_stage_row<T>(i) * Mp + k);
+  }
+  template <class Acc>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int, int, ECtx&, int wr, int wc, int lane) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -114,8 +224,8 @@ template <typename T> struct FwdWProb {
         if (m >= nrows) continue;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int n = n0 + nt_acc_col(wc, b, lane);
-          if (n < Mp) W[m * Mp + n] = acc[a][b][r];
+          const int k = nt_acc_col(wc, b, lane);
+          if (k < K) loc[(int64_t)k * ldk + m] = acc[a][b][r];
         }
       }
   }
@@ -123,8 +233,9 @@ template <typename T> struct FwdWProb {
 };
 
 // (2) T_k = W S_k (never stored) -> tt[k][n] = sum_j T_k[n][j]^2 ; one workgroup walks all column tiles
-template <typename T> struct FwdTProb {
+template <typename T> struct FwdTProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = false;
   const T* W; int64_t nrows; int Mp;
   const T* ST;                     // [K][Mp][Mp], ST[k][j][i] = S_k[i][j]
   T* tt; int64_t ldt;              // [K][ldt]
@@ -132,8 +243,9 @@ template <typename T> struct FwdTProb {
   struct ECtx { T rs[4][4]; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return true; }
+  __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const { kb = n0; ke = Mp; }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const {
 #pragma unroll
     for (int i = 0; i < NTCfg<T>::VPT; ++i) {
       const int64_t r = m0 + nt_stage_row<T>(i);
@@ -149,7 +261,7 @@ template <typename T> struct FwdTProb {
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
     return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
-  __device__ __forceinline__ V loadB(int n0, int i, int k, int bz) const {
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int, int bz) const {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(ST + ((int64_t)bz * Mp + c) * Mp + k) : vzero<T>();
   }
@@ -164,25 +276,7 @@ template <typename T> struct FwdTProb {
   }
   __device__ __forceinline__ void finish(int64_t m0, int bz, ECtx& e, char* smem, int wr, int wc, int lane) const {
     T* rsum = reinterpret_cast<T*>(smem);      // [128]
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e.rs[a][r] = group16_sum(e.rs[a][r]);
-    if (wc == 0 && (lane & 15) == 0) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rsum[nt_acc_row<T>(wr, a, lane, r)] = e.rs[a][r];
-    }
-    __syncthreads();
-    if (wc == 1 && (lane & 15) == 0) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rsum[nt_acc_row<T>(wr, a, lane, r)] += e.rs[a][r];
-    }
-    __syncthreads();
+    nt_rowsum_finish<T>(e.rs, rsum, wr, wc, lane);
     if (threadIdx.x < GDRF_TILE) {
       const int64_t m = m0 + threadIdx.x;
       if (m < nrows) tt[(int64_t)bz * ldt + m] = rsum[threadIdx.x];
@@ -190,43 +284,43 @@ template <typename T> struct FwdTProb {
   }
 };
 
-// (3) Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W ; reduction index = (k, i)
-template <typename T> struct BwdWbarProb {
+// (3) Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W.  One staged chunk of W serves all K
+//     topics (a_reuse = K): the per-(topic,row) factor 2 vbar_kn sits in an LDS table and scales the A fragments.
+template <typename T> struct BwdWbarProb : NTXcdMap {
   using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = true;
   const T* W; int64_t nrows; int M, Mp, K;
   const T* Bm;                     // [K][Mp][Mp] symmetric B_k = S_k S_k^T
   const T* vbar; const T* locbar; int64_t ldk;   // [K][ldk]
   const T* asum;                   // [nrows] a_n * sum_k vbar_kn
   const T* U;                      // [K][M] u_loc (unpadded)
   T* Wbar;
-  struct ACtx { const T* p[NTCfg<T>::VPT]; int64_t r[NTCfg<T>::VPT]; };
+  struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx {};
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
-  __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = K * Mp; }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+  __device__ __forceinline__ int a_reuse() const { return K; }
+  __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = Mp; }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char* extra) const {
+    T* sc = reinterpret_cast<T*>(extra);          // [K][128]
+    for (int e = threadIdx.x; e < K * GDRF_TILE; e += 256) {
+      const int k = e / GDRF_TILE, r = e - k * GDRF_TILE;
+      sc[e] = (m0 + r < nrows) ? T(2) * vbar[(int64_t)k * ldk + m0 + r] : T(0);
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NTCfg<T>::VPT; ++i) {
       const int64_t r = m0 + nt_stage_row<T>(i);
-      c.r[i] = r;
       c.p[i] = (r < nrows) ? W + r * Mp : nullptr;
     }
   }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
-    if (!c.p[i]) return vzero<T>();
-    const int kk = k / Mp, ii = k - kk * Mp;
-    V v = *reinterpret_cast<const V*>(c.p[i] + ii);
-    const T s = T(2) * vbar[(int64_t)kk * ldk + c.r[i]];
-#pragma unroll
-    for (int e = 0; e < Vec16<T>::N; ++e) v[e] *= s;
-    return v;
+    return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
-  __device__ __forceinline__ V loadB(int n0, int i, int k, int) const {
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int rep, int) const {
     const int c = n0 + nt_stage_row<T>(i);
-    if (c >= Mp) return vzero<T>();
-    const int kk = k / Mp, ii = k - kk * Mp;
-    return *reinterpret_cast<const V*>(Bm + ((int64_t)kk * Mp + c) * Mp + ii);
+    return (c < Mp) ? *reinterpret_cast<const V*>(Bm + ((int64_t)rep * Mp + c) * Mp + k) : vzero<T>();
   }
   template <class Acc>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
@@ -251,8 +345,9 @@ template <typename T> struct BwdWbarProb {
 };
 
 // (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
-template <typename T> struct BwdKnmProb {
+template <typename T> struct BwdKnmProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = false;
   const T* Wbar; int64_t nrows; int M, Mp, D, kind;
   const T* LinvT;                  // [Mp][Mp], LinvT[i][j] = Linv[j][i]
   const T* X; const T* Z; const Hyper* h;
@@ -261,8 +356,9 @@ template <typename T> struct BwdKnmProb {
   struct ECtx { T s1, s2; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const { kb = n0; ke = Mp; }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int) const {
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const {
 #pragma unroll
     for (int i = 0; i < NTCfg<T>::VPT; ++i) {
       const int64_t r = m0 + nt_stage_row<T>(i);
@@ -273,7 +369,7 @@ template <typename T> struct BwdKnmProb {
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
     return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
-  __device__ __forceinline__ V loadB(int n0, int i, int k, int) const {
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int, int) const {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(LinvT + (int64_t)c * Mp + k) : vzero<T>();
   }
@@ -304,7 +400,7 @@ template <typename T> struct BwdKnmProb {
 #pragma unroll
           for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - z[b][d]; r2 += t * t; }
           r2 *= ils2;
-          const T kv = cov_from_r2<T>(kind, r2, var);
+          const T kv = cov_fast<T>(kind, r2, var);
           e.s1 += acc[a][b][r] * kv;
           e.s2 += acc[a][b][r] * dcov_dlogls<T>(kind, kv, r2, var);
         }
@@ -320,30 +416,6 @@ template <typename T> struct BwdKnmProb {
 };
 
 // =====================================================================================
-// rowstats: q_n = ||w_n||^2, loc_kn = u_k . w_n   (one wave per row)
-// =====================================================================================
-template <typename T>
-__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ W, int64_t nrows, int M, int Mp, int K,
-                                                       const T* __restrict__ U, T* __restrict__ q, T* __restrict__ loc, int64_t ldk) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t n = wave; n < nrows; n += nwaves) {
-    const T* w = W + n * Mp;
-    T s = 0;
-    for (int i = lane; i < M; i += 64) { const T t = w[i]; s += t * t; }
-    s = wave_sum(s);
-    if (lane == 0) q[n] = s;
-    for (int k = 0; k < K; ++k) {
-      T d = 0;
-      for (int i = lane; i < M; i += 64) d += w[i] * U[(int64_t)k * M + i];
-      d = wave_sum(d);
-      if (lane == 0) loc[(int64_t)k * ldk + n] = d;
-    }
-  }
-}
-
-// =====================================================================================
 // elbo_rows: per observation: variance, reparameterised draw, softmax link, Multinomial
 // log-likelihood, both Normal site terms, and the row-local part of the backward.
 // One thread per row, K <= GDRF_KMAX kept in registers.
@@ -353,9 +425,10 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ W, 
 template <typename T>
 __global__ __launch_bounds__(128) void elbo_rows_kernel(
     int64_t nrows, int K, int V, const Hyper* __restrict__ h,
-    const T* __restrict__ q, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps, int64_t ldk, int64_t lde,
+    const T* __restrict__ qpart, int nqpart, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps,
+    int64_t ldk, int64_t lde,
     const int32_t* __restrict__ ws, const T* __restrict__ phi,
-    T* __restrict__ vbar, T* __restrict__ locbar, T* __restrict__ asum, T* __restrict__ mu_out,
+    T* __restrict__ qout, T* __restrict__ vbar, T* __restrict__ locbar, T* __restrict__ asum, T* __restrict__ mu_out,
     double* __restrict__ dpart /*[grid][4]*/, T* __restrict__ phibar_part /*[grid][K*V]*/) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int RB = blockDim.x;
@@ -378,7 +451,9 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     T v[GDRF_KMAX], mu[GDRF_KMAX], ep[GDRF_KMAX];
     T a = 0, vd = 0;
     if (ok) {
-      const T qn = q[n];
+      T qn = 0;
+      for (int c = 0; c < nqpart; ++c) qn += qpart[(int64_t)c * ldk + n];
+      qout[n] = qn;
       a = (var - qn > T(0)) ? T(1) : T(0);
       const T v0 = a * (var - qn);
       T mx = -3.0e38f;

@@ -138,7 +138,7 @@ class Engine:
             return flat.view(self.K, self.V).clone()
         raise KeyError(name)
 
-    TIMING_SLOTS = ("factorize", "k_nm", "transforms", "fwd_w", "rowstats", "fwd_t", "elbo_rows", "bwd_wbar", "bwd_knm",
+    TIMING_SLOTS = ("factorize", "k_nm", "transforms", "fwd_w", "loc", "fwd_t", "elbo_rows", "bwd_wbar", "bwd_knm",
                     "tn_sym", "tn_gt", "slab_reduce", "ubar", "step_finish", "adam")
 
     def set_timing(self, enable: bool):

@@ -96,7 +96,7 @@ int gdrf_ws_ptr(gdrf_ctx* ctx, int which, void** ptr, int64_t* nelem);
 int gdrf_ws_copy(gdrf_ctx* ctx, int which, void* dst_dev, int64_t nelem, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).  Slots:
- * 0 factorize, 1 k_nm, 2 transforms+B_k, 3 fwd_w, 4 rowstats, 5 fwd_t, 6 elbo_rows, 7 bwd_wbar,
+ * 0 factorize, 1 k_nm, 2 transforms+B_k, 3 fwd_w, 4 loc (W U^T), 5 fwd_t, 6 elbo_rows, 7 bwd_wbar,
  * 8 bwd_knm, 9 tn_sym (A_k), 10 tn_gt, 11 slab reductions, 12 ubar, 13 step_finish, 14 adam.
  * gdrf_get_timing synchronises on the recorded events and returns accumulated ms and counts. */
 int gdrf_set_timing(gdrf_ctx* ctx, int enable);

@@ -338,35 +338,29 @@ def _np_dk_dlogls(kind, k, r2, var):
     return var * np.exp(-a) * (a / 3.0) * (1 + a) * SQRT5 * (r2 / r)
 
 
-def fused_elbo_and_grads(kind, xs, ws, Z, params: Dict[str, np.ndarray], alpha, eps, jitter_total_: float,
-                         n_global: Optional[int] = None):
-    """Returns (loss, grads-of-loss wrt unconstrained params, aux) using:
-       W = Knm Linv^T ; T_k = W S_k (forward variance) ;
-       Wbar = sum_k diag(2 vbar_k) W B_k (+ loc and clamp terms), B_k = S_k S_k^T ;
-       A_k = W^T diag(vbar_k) W ; Sbar_k = 2 A_k S_k ; G = Wbar^T W ; Lbar = -tril(Linv^T G) ;
-       Cholesky backward through the explicit inverse."""
-    xs = np.asarray(xs)
-    dt = xs.dtype
-    ws_f = np.asarray(ws).astype(dt)
-    N, D = xs.shape
-    M = Z.shape[0]
+def _np_transforms(params):
     K = params["u_loc"].shape[0]
-    ng = float(n_global if n_global is not None else N)
-    ls = np.exp(params["log_lengthscale"])
-    var = np.exp(params["log_variance"])
-    eta = np.exp(params["log_noise"])
-    U = params["u_loc"]
+    M = params["u_loc"].shape[1]
     Sunc = params["u_scale_tril_unc"]
     S = np.tril(Sunc, -1) + np.stack([np.diag(np.exp(np.diag(Sunc[k]))) for k in range(K)])
     phi_unc = params["phi_unc"]
     phi = np.exp(phi_unc - phi_unc.max(-1, keepdims=True))
     phi = phi / phi.sum(-1, keepdims=True)
-    # ---- M x M prologue
-    Kuu0, R2uu = _np_kernel(kind, Z, Z, ls, var)
+    return (np.exp(params["log_lengthscale"]), np.exp(params["log_variance"]), np.exp(params["log_noise"]), S, phi, K, M)
+
+
+def fused_local(kind, xs, ws, Z, params: Dict[str, np.ndarray], eps, jitter_total_: float):
+    """Everything of one step that is a sum over THIS shard's observations: the all-reduce payload
+    (what gdrf_step_local writes to red_T / red_d) plus the stage values (aux)."""
+    xs = np.asarray(xs)
+    dt = xs.dtype
+    ws_f = np.asarray(ws).astype(dt)
+    ls, var, eta, S, phi, K, M = _np_transforms(params)
+    U = params["u_loc"]
+    Kuu0, _ = _np_kernel(kind, Z, Z, ls, var)
     Kuu = Kuu0 + jitter_total_ * np.eye(M, dtype=dt)
     L = np.linalg.cholesky(Kuu)
     Linv = np.linalg.inv(L)
-    # ---- N side forward
     Knm, R2nm = _np_kernel(kind, xs, Z, ls, var)
     W = Knm @ Linv.T
     q = (W * W).sum(-1)
@@ -389,53 +383,77 @@ def fused_elbo_and_grads(kind, xs, ws, Z, params: Dict[str, np.ndarray], alpha, 
     logit = np.log(np.clip(phat, feps, 1 - feps))
     from scipy.special import gammaln
     ll_const = float((gammaln(ws_f.sum(-1).astype(np.float64) + 1) - gammaln(ws_f.astype(np.float64) + 1).sum(-1)).sum())
-    ll = ll_const + float((ws_f * logit).sum())
+    llw = float((ws_f * logit).sum())
     c_site = -np.log(s) + np.log(v) - 0.5 * eps ** 2 * r ** 2 + 0.5 * eps ** 2
-    a64 = np.asarray(alpha, dtype=np.float64)
-    lp_phi = float((gammaln(a64.sum(-1)) - gammaln(a64).sum(-1) + ((a64 - 1) * np.log(phi)).sum(-1)).sum())
-    elbo_n = float(c_site.sum()) + ll + lp_phi
-    loss = -elbo_n / ng
-    # ---- backward (of ELBO*N)
     pbar = ws_f * mask / p
     thbar = phi @ pbar.T                                  # (K,N)
-    phibar = theta @ pbar + (np.asarray(alpha, dtype=dt) - 1) / phi
     mubar = theta * (thbar - (theta * thbar).sum(0, keepdims=True))
     dc_dv = -1 / s + 1 / v - eps ** 2 * r * eta / s ** 2
     dc_deta = -1 / s + eps ** 2 * r ** 2 / s
     vbar = mubar * eps + dc_dv
     locbar = mubar
-    ubar = locbar @ W                                     # (K,M)
     B = np.einsum("kij,klj->kil", S, S)                   # S_k S_k^T
     Wbar = locbar.T @ U - 2 * (a * vbar.sum(0))[:, None] * W
     for k in range(K):
         Wbar += (2 * vbar[k])[:, None] * (W @ B[k])
-    A = np.einsum("ni,kn,nj->kij", W, vbar, W)
-    Sbar = 2 * np.einsum("kij,kjl->kil", A, S)
-    var_direct = float((a * vbar.sum(0)).sum())
     Knm_bar = Wbar @ Linv
-    G = Wbar.T @ W
-    Lbar = -np.tril(Linv.T @ G)
+    payload = dict(
+        site=float(c_site.sum()), llw=llw, ll_const=ll_const, noise_g=float(dc_deta.sum()),
+        var_direct=float((a * vbar.sum(0)).sum()), knm_k=float((Knm_bar * Knm).sum()),
+        knm_dls=float((Knm_bar * _np_dk_dlogls(kind, Knm, R2nm, var)).sum()),
+        ubar=locbar @ W, phibar_lik=theta @ pbar, A=np.einsum("ni,kn,nj->kij", W, vbar, W), G=Wbar.T @ W)
+    aux = dict(W=W, q=q, loc=loc, tt=tt, var=v, mu=mu, theta=theta, vbar=vbar, locbar=locbar, Wbar=Wbar, Knm=Knm, Kuu=Kuu,
+               L=L, Linv=Linv, phi=phi, S=S, B=B)
+    return payload, aux
+
+
+def fused_finish(kind, Z, params: Dict[str, np.ndarray], alpha, payload, n_global: float, jitter_total_: float):
+    """Replicated epilogue on the (all-reduced) payload: what gdrf_step_finish computes."""
+    dt = Z.dtype
+    ls, var, eta, S, phi, K, M = _np_transforms(params)
+    from scipy.special import gammaln
+    Kuu0, R2uu = _np_kernel(kind, Z, Z, ls, var)
+    L = np.linalg.cholesky(Kuu0 + jitter_total_ * np.eye(M, dtype=dt))
+    Linv = np.linalg.inv(L)
+    a64 = np.asarray(alpha, dtype=np.float64)
+    lp_phi = float((gammaln(a64.sum(-1)) - gammaln(a64).sum(-1) + ((a64 - 1) * np.log(phi)).sum(-1)).sum())
+    elbo_n = payload["site"] + payload["llw"] + payload["ll_const"] + lp_phi
+    loss = -elbo_n / n_global
+    Sbar = 2 * np.einsum("kij,kjl->kil", payload["A"], S)
+    Lbar = -np.tril(Linv.T @ payload["G"])
     Pm = np.tril(L.T @ Lbar)
     Pm[np.diag_indices(M)] *= 0.5
     Sp = Linv.T @ Pm @ Linv
     Kuu_bar = 0.5 * (Sp + Sp.T)
-    g_logvar = float((Knm_bar * Knm).sum() + (Kuu_bar * Kuu0).sum() + var * var_direct)
-    g_logls = float((Knm_bar * _np_dk_dlogls(kind, Knm, R2nm, var)).sum()
-                    + (Kuu_bar * _np_dk_dlogls(kind, Kuu0, R2uu, var)).sum())
-    g_lognoise = float(eta * dc_deta.sum())
+    g_logvar = payload["knm_k"] + float((Kuu_bar * Kuu0).sum()) + var * payload["var_direct"]
+    g_logls = payload["knm_dls"] + float((Kuu_bar * _np_dk_dlogls(kind, Kuu0, R2uu, var)).sum())
+    g_lognoise = float(eta * payload["noise_g"])
     g_Sunc = np.tril(Sbar, -1)
     for k in range(K):
         g_Sunc[k][np.diag_indices(M)] = np.diag(Sbar[k]) * np.diag(S[k])
+    phibar = payload["phibar_lik"] + (np.asarray(alpha, dtype=dt) - 1) / phi
     g_phiunc = phi * (phibar - (phi * phibar).sum(-1, keepdims=True))
-    sc = -1.0 / ng
+    sc = -1.0 / n_global
     grads = dict(
         log_lengthscale=np.asarray(sc * g_logls), log_variance=np.asarray(sc * g_logvar),
-        u_loc=sc * ubar, u_scale_tril_unc=sc * g_Sunc, log_noise=np.asarray(sc * g_lognoise),
+        u_loc=sc * payload["ubar"], u_scale_tril_unc=sc * g_Sunc, log_noise=np.asarray(sc * g_lognoise),
         phi_unc=sc * g_phiunc,
     )
-    aux = dict(W=W, q=q, loc=loc, tt=tt, var=v, mu=mu, theta=theta, vbar=vbar, locbar=locbar, Wbar=Wbar,
-               A=A, G=G, Knm=Knm, Kuu=Kuu, L=L, Linv=Linv, ll=ll, ll_const=ll_const, lp_phi=lp_phi,
-               site=float(c_site.sum()), elbo_n=elbo_n, Kuu_bar=Kuu_bar, phi=phi, S=S, B=B)
+    return loss, grads, dict(lp_phi=lp_phi, elbo_n=elbo_n, Kuu_bar=Kuu_bar)
+
+
+def fused_elbo_and_grads(kind, xs, ws, Z, params: Dict[str, np.ndarray], alpha, eps, jitter_total_: float,
+                         n_global: Optional[int] = None):
+    """Returns (loss, grads-of-loss wrt unconstrained params, aux) in the factorisation of the HIP kernels:
+       W = Knm Linv^T ; T_k = W S_k (forward variance) ;
+       Wbar = sum_k diag(2 vbar_k) W B_k (+ loc and clamp terms), B_k = S_k S_k^T ;
+       A_k = W^T diag(vbar_k) W ; Sbar_k = 2 A_k S_k ; G = Wbar^T W ; Lbar = -tril(Linv^T G) ;
+       Cholesky backward through the explicit inverse."""
+    payload, aux = fused_local(kind, xs, ws, Z, params, eps, jitter_total_)
+    ng = float(n_global if n_global is not None else np.asarray(xs).shape[0])
+    loss, grads, fin = fused_finish(kind, np.asarray(Z), params, alpha, payload, ng, jitter_total_)
+    aux.update(A=payload["A"], G=payload["G"], ll=payload["llw"] + payload["ll_const"], ll_const=payload["ll_const"],
+               site=payload["site"], **fin)
     return loss, grads, aux
 
 

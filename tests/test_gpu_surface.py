@@ -1,0 +1,131 @@
+"""GPU: the reference's Python surface for the hot path, used the way gdrf/train_script.py uses it."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from gdrf_amd.data import synth_circles
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(dtype=torch.float32, K=4, V=20, n_points=(6, 5), W=30, H=20, opt="adamw", kernel="rbf", seed=3, jitter=1e-6):
+    from gdrf_amd import poutine
+    from gdrf_amd.infer import OBJECTIVE_DICT, SVI
+    from gdrf_amd.kernels import KERNEL_DICT
+    from gdrf_amd.models import GDRF_MODEL_DICT
+    from gdrf_amd.optim import OPTIMIZER_DICT
+    xs_np, ws_np, _ = synth_circles(W, H, V, K, seed=seed)
+    device = "cuda:0"
+    xs = torch.from_numpy(xs_np).float().to(device)                 # train_script.py:264-268
+    ws = torch.from_numpy(ws_np).int().to(device)
+    world = list(zip(xs.min(dim=0).values.cpu().numpy().tolist(), xs.max(dim=0).values.cpu().numpy().tolist()))
+    kern = KERNEL_DICT[kernel](input_dim=2, lengthscale=torch.tensor(0.2).to(device), variance=torch.tensor(25.0).to(device)).to(device)
+    model = GDRF_MODEL_DICT["sparsemultinomialgdrf"](
+        xs=xs, ws=ws, world=world, kernel=kern, num_observation_categories=V, device=device, num_topic_categories=K,
+        dirichlet_param=0.01, n_points=list(n_points), fixed_inducing_points=True, inducing_init="grid", maxjitter=15,
+        jitter=jitter, randomize_wt_matrix=False, dtype=dtype, seed=seed)
+    optimizer = OPTIMIZER_DICT[opt]({"lr": 0.01})
+    objective = OBJECTIVE_DICT["graphelbo"](max_plate_nesting=1, vectorize_particles=True, num_particles=1)
+    scale = poutine.scale(scale=1.0 / len(xs))
+    svi = SVI(model=scale(model.model), guide=scale(model.guide), optim=optimizer, loss=objective)
+    return model, svi, optimizer, xs, ws
+
+
+def test_known_answers_at_initialisation():
+    model, svi, _, xs, ws = _build()
+    tp = model.topic_probs(xs)
+    assert tp.shape == (len(xs), model.K) and torch.allclose(tp, torch.full_like(tp, 1.0 / model.K), atol=1e-6)     # A.6(1)
+    assert abs(float(model.perplexity(xs, ws).item()) - model.V) < 1e-3 * model.V                                  # A.6(2)
+    assert torch.allclose(model.word_topic_matrix, torch.full((model.K, model.V), 1.0 / model.V, device=xs.device), atol=1e-6)
+    assert model.word_probs(xs).shape == (len(xs), model.V) and model.log_topic_probs(xs).shape == (model.K, len(xs))
+    assert abs(float(model.kernel_lengthscale) - 0.2) < 1e-6 and abs(float(model.kernel_variance) - 25.0) < 1e-4
+    assert model.dims == 2
+    ust = model.u_scale_tril
+    assert torch.allclose(ust[0], ust[-1]) and float(ust[0].triu(1).abs().max()) == 0.0
+
+
+def test_training_loop_like_train_script_improves_the_fit():
+    model, svi, opt, xs, ws = _build()
+    p0 = float(model.perplexity(xs, ws).item())
+    losses = []
+    for epoch in range(40):
+        model.train()
+        losses.append(svi.step(xs=xs, ws=ws, subsample=False))
+        model.eval()
+    p1 = float(model.perplexity(xs, ws).item())
+    assert all(np.isfinite(losses)) and p1 < p0 and np.mean(losses[-5:]) < np.mean(losses[:5])
+    # checkpoint surface: deepcopy(model).half(), state_dict round trip, optimizer state
+    ckpt = {"model": copy.deepcopy(model).half(), "optimizer": opt.get_state()}
+    sd = ckpt["model"].float().state_dict()
+    assert set(sd) == {"_kernel.lengthscale_unconstrained", "_kernel.variance_unconstrained", "noise_unconstrained",
+                       "u_loc_unconstrained", "_word_topic_matrix_map_unconstrained", "u_scale_tril_unconstrained"}
+    model2, svi2, opt2, _, _ = _build()
+    model2.load_state_dict(model.state_dict(), strict=False)
+    opt2.set_state(opt.get_state())
+    assert abs(float(model2.perplexity(xs, ws).item()) - p1) < 1e-5 * p1
+    eps = torch.randn(model.K, len(xs), generator=torch.Generator().manual_seed(1))
+    a = svi.step(xs=xs, ws=ws, subsample=False, eps=eps)
+    b = svi2.step(xs=xs, ws=ws, subsample=False, eps=eps)
+    assert abs(a - b) < 1e-6 * abs(a)
+    assert opt2.get_state()["u_loc"]["step"] == opt.get_state()["u_loc"]["step"] == 41
+
+
+def test_streaming_minibatch_steps_keep_the_global_scale():
+    """train_script.py:394-465: tiny mini-batches, scale stays 1/len(full xs) (quirk Q9)."""
+    model, svi, _, xs, ws = _build()
+    rng = np.random.default_rng(0)
+    for epoch in range(5):
+        sel = rng.choice(epoch + 3, size=3)
+        loss = svi.step(xs=xs[sel, ...], ws=ws[sel, ...], subsample=False)
+        assert np.isfinite(loss)
+    one = svi.step(xs=xs[5].unsqueeze(0), ws=ws[5].unsqueeze(0), subsample=False)          # streaming_size <= 1
+    assert np.isfinite(one)
+
+
+def test_inputs_outside_the_world_are_rejected():
+    model, svi, _, xs, ws = _build()
+    with pytest.raises(AssertionError):
+        model.topic_probs(xs + 2.0)
+
+
+def test_free_running_eps_is_reproducible_for_a_seed():
+    m1, s1, _, xs, ws = _build(seed=9)
+    m2, s2, _, _, _ = _build(seed=9)
+    a = [s1.step(xs=xs, ws=ws) for _ in range(3)]
+    b = [s2.step(xs=xs, ws=ws) for _ in range(3)]
+    assert a == b
+
+
+def _dist_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share the box's single GPU
+    model, svi, _, xs, ws = _build(dtype=torch.float64)
+    N = len(xs)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    svi.row_offset = lo
+    losses = [svi.step(xs=xs[lo:hi], ws=ws[lo:hi], subsample=False) for _ in range(3)]
+    torch.save({"losses": losses, "params": model._engine.params.cpu()}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_dist_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    model, svi, _, xs, ws = _build(dtype=torch.float64)
+    ref = [svi.step(xs=xs, ws=ws, subsample=False) for _ in range(3)]
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
+    assert r0["losses"] == r1["losses"]
+    assert np.allclose(r0["losses"], ref, rtol=1e-10)                      # Philox keyed by the global row: same eps
+    assert torch.equal(r0["params"], r1["params"])
+    assert (r0["params"] - model._engine.params.cpu()).abs().max() < 1e-9
