@@ -24,6 +24,7 @@ SIGNATURES = {
     "gdrf_knm": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gdrf_fill_eps": (_int, [_vp, C.c_uint64, C.c_uint32, _i64, _i64, _vp, _vp]),
     "gdrf_ll_const": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), _vp]),
+    "gdrf_probe": (_int, [_vp, _vp, _vp, _dbl, _vp]),
     "gdrf_factorize": (_int, [_vp, _vp, _vp, _dbl, _vp]),
     "gdrf_step_local": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gdrf_step_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
@@ -31,6 +32,7 @@ SIGNATURES = {
     "gdrf_predict": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "gdrf_chol_failed": (_int, [_vp, C.POINTER(_int), _vp]),
     "gdrf_ws_ptr": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_i64)]),
+    "gdrf_ws_elem_size": (_int, [_vp, _int]),
     "gdrf_ws_copy": (_int, [_vp, _int, _vp, _i64, _vp]),
     "gdrf_set_timing": (_int, [_vp, _int]),
     "gdrf_get_timing": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64), _int]),

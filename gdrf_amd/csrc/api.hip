@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace gdrf;
@@ -32,20 +33,27 @@ static int fail(int code, const char* what, const char* detail) {
   } while (0)
 
 #define GDRF_NSLOTS 16
+// dtype of a context: N-side element type T / solve element type TS
+//   GDRF_F32 (0): T = float, TS = double  (default fp32 mode: K-fold contractions on f32 MFMA, the ill-conditioned
+//                 pieces -- K_uu, Cholesky, L^-1, the solve W = K_nm L^-T, its backward, the M x M epilogue -- in f64)
+//   GDRF_F64 (1): T = TS = double
+//   GDRF_F32_PURE (2): T = TS = float (everything in fp32, as the reference's .float() casts do; for A/B comparisons)
 struct gdrf_ctx {
   int dev, M, Mp, K, V, D, dtype, kind;
   int64_t ncap, ldk;          // ldk = leading dimension of the (K, n) arrays
-  size_t esz;
+  size_t esz, ssz;            // element sizes: N side, solve side
   int nt;                     // 128-wide tiles over Mp
   int nsplit_cap;
-  // M x M (ld Mp)
-  void *Kuu, *Lw, *L, *LT, *Linv, *LinvT, *Dinv, *S, *ST, *Bm, *t0, *t1, *t2, *Sbar;
-  void *phi, *Cf, *Upad, *qpart;
-  // N side
+  // solve precision, M x M (ld Mp)
+  void *Kuu, *Lw, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *Zs, *GTs;
+  // probe (N-side precision) scratch, only when T != TS
+  void *pK, *pL;
+  double probe_jitter; int probe_ok;
+  // N-side precision
+  void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
-  // partials
   void *slab, *ubar_part, *phibar_part;
-  double *dpart, *dsmall;     // dsmall: [0..1] kuu sums, [2..9] scratch
+  double *dpart, *dsmall;     // dsmall: [0..1] kuu sums, [8] ll_const scratch
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
   double* alpha_dev; double lgam_const;
   Hyper* hyp; int* flag;
@@ -118,17 +126,19 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   if (!out || n_cap < 1 || M < 1 || K < 1 || V < 1 || D < 1) return fail(-1, "gdrf_ctx_create", "bad size");
   if (K > GDRF_KMAX) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 32 not supported");
   if (D > GDRF_DMAX) return fail(-1, "gdrf_ctx_create", "more than 4 input dimensions not supported");
-  if (dtype != GDRF_F32 && dtype != GDRF_F64) return fail(-1, "gdrf_ctx_create", "dtype");
+  if (dtype != GDRF_F32 && dtype != GDRF_F64 && dtype != GDRF_F32_PURE) return fail(-1, "gdrf_ctx_create", "dtype");
   if (kernel_id != GDRF_RBF && kernel_id != GDRF_MATERN52) return fail(-1, "gdrf_ctx_create", "kernel_id");
   HIPCHK(hipSetDevice(device));
   gdrf_ctx* c = new gdrf_ctx();
   c->dev = device; c->M = M; c->Mp = (int)round_up(M, GDRF_MPAD); c->K = K; c->V = V; c->D = D;
   c->dtype = dtype; c->kind = kernel_id; c->ncap = n_cap; c->ldk = round_up(n_cap, 4);
-  c->esz = dtype == GDRF_F32 ? 4 : 8;
+  c->esz = dtype == GDRF_F64 ? 8 : 4;
+  c->ssz = dtype == GDRF_F32_PURE ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
-  c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
+  c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0; c->probe_ok = 0; c->probe_jitter = -1;
+  c->pK = c->pL = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
-  const size_t mm = (size_t)c->Mp * c->Mp * c->esz;
+  const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
     if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc", hipGetErrorString(e));
@@ -137,11 +147,13 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   };
   int rc = 0;
 #define AL(ptr, bytes) if ((rc = A((void**)&(ptr), (bytes)))) { gdrf_ctx_destroy(c); return rc; }
-  AL(c->Kuu, mm) AL(c->Lw, mm) AL(c->L, mm) AL(c->LT, mm) AL(c->Linv, mm) AL(c->LinvT, mm)
-  AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->esz)
+  AL(c->Kuu, mms) AL(c->Lw, mms) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
+  AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->ssz)
+  AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
+  AL(c->Cf, (size_t)K * M * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
+  if (c->esz != c->ssz) { AL(c->pK, mm) AL(c->pL, mm) }
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
-  AL(c->t0, mm) AL(c->t1, mm) AL(c->t2, mm)
-  AL(c->phi, (size_t)K * V * c->esz) AL(c->Cf, (size_t)K * M * c->esz)
+  AL(c->phi, (size_t)K * V * c->esz)
   AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)c->nt * c->ldk * c->esz)
   AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
   AL(c->q, (size_t)c->ldk * c->esz) AL(c->asum, (size_t)c->ldk * c->esz)
@@ -193,24 +205,27 @@ int gdrf_set_dirichlet(gdrf_ctx* c, const double* alpha) {
   return 0;
 }
 
-int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) {
+// which = 0 W, 1 Wbar, 2 q, 3 loc, 4 tt, 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST
+static int ws_lookup(gdrf_ctx* c, int which, void** ptr, int64_t* nelem, int* esz) {
   const int64_t mm = (int64_t)c->Mp * c->Mp, kn = (int64_t)c->K * c->ldk;
-  void* p = nullptr; int64_t n = 0;
+  void* p = nullptr; int64_t n = 0; int e = (int)c->esz;
   switch (which) {
     case 0: p = c->W; n = c->ncap * c->Mp; break;     case 1: p = c->Wbar; n = c->ncap * c->Mp; break;
     case 2: p = c->q; n = c->ldk; break;              case 3: p = c->loc; n = kn; break;
     case 4: p = c->tt; n = kn; break;                 case 5: p = c->vbar; n = kn; break;
     case 6: p = c->locbar; n = kn; break;             case 7: p = c->asum; n = c->ldk; break;
-    case 8: p = c->Kuu; n = mm; break;                case 9: p = c->L; n = mm; break;
-    case 10: p = c->Linv; n = mm; break;              case 11: p = c->S; n = mm * c->K; break;
+    case 8: p = c->Kuu; n = mm; e = (int)c->ssz; break;   case 9: p = c->L; n = mm; e = (int)c->ssz; break;
+    case 10: p = c->Linv; n = mm; e = (int)c->ssz; break; case 11: p = c->S; n = mm * c->K; break;
     case 12: p = c->Bm; n = mm * c->K; break;         case 13: p = c->phi; n = (int64_t)c->K * c->V; break;
-    case 14: p = c->mu; n = kn; break;                case 15: p = c->LinvT; n = mm; break;
+    case 14: p = c->mu; n = kn; break;                case 15: p = c->LinvT; n = mm; e = (int)c->ssz; break;
     case 16: p = c->ST; n = mm * c->K; break;
     default: return fail(-1, "gdrf_ws_ptr", "unknown buffer id");
   }
-  *ptr = p; *nelem = n;
+  *ptr = p; *nelem = n; *esz = e;
   return 0;
 }
+int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) { int e; return ws_lookup(c, which, ptr, nelem, &e); }
+int gdrf_ws_elem_size(gdrf_ctx* c, int which) { void* p; int64_t n; int e; return ws_lookup(c, which, &p, &n, &e) ? -1 : e; }
 
 int gdrf_set_timing(gdrf_ctx* c, int enable) {
   c->timing = enable;
@@ -233,43 +248,72 @@ int gdrf_get_timing(gdrf_ctx* c, double* ms_out, int64_t* cnt_out, int nslots) {
 
 int gdrf_ws_copy(gdrf_ctx* c, int which, void* dst, int64_t nelem, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
-  void* p; int64_t n;
-  int rc = gdrf_ws_ptr(c, which, &p, &n);
+  void* p; int64_t n; int e;
+  int rc = ws_lookup(c, which, &p, &n, &e);
   if (rc) return rc;
   if (nelem > n) return fail(-1, "gdrf_ws_copy", "nelem exceeds the buffer");
-  HIPCHK(hipMemcpyAsync(dst, p, (size_t)nelem * c->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIPCHK(hipMemcpyAsync(dst, p, (size_t)nelem * e, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct Impl {
+// T = N-side element type, TS = solve element type
+template <typename T, typename TS> struct Impl {
   using C = NTCfg<T>;
+  using CS = NTCfg<TS>;
+  static constexpr bool kSame = std::is_same<T, TS>::value;
   static T* P(void* p) { return reinterpret_cast<T*>(p); }
   static const T* P(const void* p) { return reinterpret_cast<const T*>(p); }
+  static TS* Q(void* p) { return reinterpret_cast<TS*>(p); }
 
-  static int mm_nt(gdrf_ctx* c, const T* A, int64_t abs_, const T* Bt, int64_t bbs, T* Cm, int64_t cbs, T alpha, int batch,
+  template <typename E>
+  static int mm_nt(gdrf_ctx* c, const E* A, int64_t abs_, const E* Bt, int64_t bbs, E* Cm, int64_t cbs, E alpha, int batch,
                    hipStream_t s) {
-    MMProb<T> p{{}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
+    MMProb<E> p{{}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
     dim3 grid(c->nt * c->nt, batch);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, MMProb<T>>), grid, dim3(256), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");
     return 0;
   }
 
-  // hyper -> Kuu(+jitter) -> Cholesky(flag) -> L, LT -> Linv, LinvT
-  static int prologue(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
+  // one Cholesky attempt in the N-side precision (what the reference's fp32 torch.linalg.cholesky would see)
+  static int probe(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
     const int Mp = c->Mp, M = c->M;
     ScopedTimer tm(c, 0, s);
     HIPCHK(hipMemsetAsync(c->flag, 0, 16, s));
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     dim3 g2((Mp + 255) / 256, Mp);
-    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp, jitter, P(c->Kuu));
-    HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(T), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(chol_kernel<T>, dim3(1), dim3(1024), 0, s, P(c->Lw), M, Mp, c->flag);
-    hipLaunchKernelGGL(finalize_l_kernel<T>, g2, dim3(256), 0, s, P(c->Lw), M, Mp, P(c->L), P(c->LT));
-    hipLaunchKernelGGL(trinv_diag_kernel<T>, dim3(Mp / 32), dim3(64), 0, s, P(c->L), M, Mp, P(c->Dinv));
-    hipLaunchKernelGGL(trinv_cols_kernel<T>, dim3(Mp / 32), dim3(1024), 0, s, P(c->L), P(c->Dinv), M, Mp, P(c->Linv), P(c->LinvT));
-    LAUNCHCHK("prologue");
+    T* K_ = kSame ? P(c->Kuu) : P(c->pK);
+    T* L_ = kSame ? P(c->Lw) : P(c->pL);
+    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp, jitter, K_);
+    HIPCHK(hipMemcpyAsync(L_, K_, (size_t)Mp * Mp * sizeof(T), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(chol_kernel<T>, dim3(1), dim3(1024), 0, s, L_, M, Mp, c->flag);
+    LAUNCHCHK("probe");
+    c->probe_jitter = jitter; c->probe_ok = 1;
+    return 0;
+  }
+
+  // K_uu(+jitter) -> Cholesky(flag) -> L, LT -> Linv, LinvT in the solve precision
+  static int factorize(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
+    const int Mp = c->Mp, M = c->M;
+    ScopedTimer tm(c, 15, s);
+    dim3 g2((Mp + 255) / 256, Mp);
+    hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
+    const int64_t nz = (int64_t)M * c->D;
+    hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, nz, Z, Q(c->Zs));
+    const bool reuse = kSame && c->probe_ok && c->probe_jitter == jitter;      // the probe already factorised this matrix
+    if (!reuse) {
+      HIPCHK(hipMemsetAsync(c->flag, 0, 16, s));
+      hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
+      HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), 0, s, Q(c->Lw), M, Mp, c->flag);
+    }
+    c->probe_ok = 0;
+    hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
+    hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, s, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
+    hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(1024), 0, s, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
+                       Q(c->LinvT));
+    LAUNCHCHK("factorize");
     return 0;
   }
 
@@ -281,8 +325,7 @@ template <typename T> struct Impl {
     int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(knm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D,
-                       c->kind, c->hyp, out, ldo);
+    hipLaunchKernelGGL(knm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D, c->kind, c->hyp, out, ldo);
     LAUNCHCHK("knm");
     return 0;
   }
@@ -301,18 +344,17 @@ template <typename T> struct Impl {
       hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
       hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
       hipLaunchKernelGGL(build_upad_kernel<T>, dim3((Mp + 255) / 256, GDRF_TILE), dim3(256), 0, s, U, K, M, Mp, P(c->Upad));
-      if ((rc = mm_nt(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
+      if ((rc = mm_nt<T>(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
     }
-
     const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
-    // (1) W = Knm Linv^T
+    // (1) W = Knm Linv^T in the solve precision, stored in the N-side precision
     {
       ScopedTimer tm(c, 3, s);
-      FwdWProb<T> p{{}, X, n, Z, M, Mp, c->D, c->kind, c->hyp, P(c->Linv), P(c->W), P(c->qpart), ldk};
-      const size_t lds = C::LDS_BYTES + (size_t)Mp * c->D * sizeof(T);
+      FwdWProb<TS, T> p{{}, X, n, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
+      const size_t lds = CS::LDS_BYTES + (size_t)Mp * c->D * sizeof(TS);
       if (lds > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FwdWProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdWProb<T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), lds, s, p);
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TS, FwdWProb<TS, T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), lds, s, p);
     }
     // loc = W U^T
     {
@@ -355,13 +397,13 @@ template <typename T> struct Impl {
         HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)round_up(rtiles * c->nt, 8)), dim3(256), lds, s, p);
     }
-    // (4) kernel hyper-parameter partials through Knm
+    // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
       ScopedTimer tm(c, 8, s);
-      BwdKnmProb<T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, P(c->LinvT), X, Z, c->hyp, c->dpart};
+      BwdKnmProb<TS, T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), X, (const TS*)Q(c->Zs), c->hyp, c->dpart};
       const int64_t nb = rtiles * c->nt;
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdKnmProb<T>>), dim3((unsigned)nb), dim3(256), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 2, redd + 4);
     }
     LAUNCHCHK("backward");
@@ -407,19 +449,22 @@ template <typename T> struct Impl {
     const T* GT = redT + roff(c, 3);
     ScopedTimer tm(c, 13, s);
     dim3 g2((Mp + 255) / 256, Mp);
+    // Cholesky / inverse backward in the solve precision
+    hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, mm, GT, Q(c->GTs));
     // HT = GT Linv ; LbarT = -triu(HT)
-    if ((rc = mm_nt(c, GT, 0, P(c->LinvT), 0, P(c->t0), 0, T(1), 1, s))) return rc;
-    hipLaunchKernelGGL(lbar_t_kernel<T>, g2, dim3(256), 0, s, P(c->t0), Mp, P(c->t1));
+    if ((rc = mm_nt<TS>(c, Q(c->GTs), 0, Q(c->LinvT), 0, Q(c->t0), 0, TS(1), 1, s))) return rc;
+    hipLaunchKernelGGL(lbar_t_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->t0), Mp, Q(c->t1));
     // Q = L^T Lbar ; P = Phi(Q)
-    if ((rc = mm_nt(c, P(c->LT), 0, P(c->t1), 0, P(c->t0), 0, T(1), 1, s))) return rc;
-    hipLaunchKernelGGL(phi_tril_kernel<T>, g2, dim3(256), 0, s, P(c->t0), Mp, P(c->t2));
+    if ((rc = mm_nt<TS>(c, Q(c->LT), 0, Q(c->t1), 0, Q(c->t0), 0, TS(1), 1, s))) return rc;
+    hipLaunchKernelGGL(phi_tril_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->t0), Mp, Q(c->t2));
     // YT = Linv^T P^T ; S' = Linv^T Y
-    if ((rc = mm_nt(c, P(c->LinvT), 0, P(c->t2), 0, P(c->t0), 0, T(1), 1, s))) return rc;
-    if ((rc = mm_nt(c, P(c->LinvT), 0, P(c->t0), 0, P(c->t1), 0, T(1), 1, s))) return rc;
-    hipLaunchKernelGGL(kuu_bar_reduce_kernel<T>, dim3(M), dim3(256), 0, s, P(c->t1), Z, M, Mp, c->D, c->kind, c->hyp, c->dpart);
+    if ((rc = mm_nt<TS>(c, Q(c->LinvT), 0, Q(c->t2), 0, Q(c->t0), 0, TS(1), 1, s))) return rc;
+    if ((rc = mm_nt<TS>(c, Q(c->LinvT), 0, Q(c->t0), 0, Q(c->t1), 0, TS(1), 1, s))) return rc;
+    hipLaunchKernelGGL(kuu_bar_reduce_kernel<TS>, dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind,
+                       c->hyp, c->dpart);
     hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)M, 2, c->dsmall);
-    // Sbar_k = 2 A_k S_k
-    if ((rc = mm_nt(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, s))) return rc;
+    // Sbar_k = 2 A_k S_k (N-side precision: well conditioned)
+    if ((rc = mm_nt<T>(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, s))) return rc;
     dim3 g3((M + 255) / 256, M, K);
     hipLaunchKernelGGL(grad_s_kernel<T>, g3, dim3(256), 0, s, P(c->Sbar), P(c->S), M, Mp, -1.0 / n_global, grads + poff(c, 5));
     hipLaunchKernelGGL(grad_small_kernel<T>, dim3(1), dim3(256), 0, s, M, Mp, K, V, c->hyp, redd, c->dsmall, ubar, phib, P(c->phi),
@@ -433,36 +478,35 @@ template <typename T> struct Impl {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
     const T* U = params + poff(c, 3);
     if (mode >= 2) hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, params + poff(c, 4), K, V, P(c->phi));
-    hipLaunchKernelGGL(predict_coeff_kernel<T>, dim3((M + 127) / 128, K), dim3(128), 0, s, P(c->Linv), U, M, Mp, K, P(c->Cf));
-    size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(T);
+    hipLaunchKernelGGL((predict_coeff_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, K, Q(c->Cf));
+    size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(TS);
     int in_lds = 1;
-    if (lds > 64 * 1024) { in_lds = 0; lds -= (size_t)K * M * sizeof(T); }
+    if (lds > 64 * 1024) { in_lds = 0; lds -= (size_t)K * M * sizeof(TS); }
     if (lds > 48 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)predict_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPCHK(hipFuncSetAttribute((const void*)predict_rows_kernel<TS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = (n + 127) / 128; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     const int64_t ldo = mode == 0 ? n : (mode == 1 ? K : V);
-    hipLaunchKernelGGL(predict_rows_kernel<T>, dim3((unsigned)blocks), dim3(128), lds, s, X, n, Z, M, c->D, c->kind, c->hyp, P(c->Cf), K,
-                       V, P(c->phi), ws, mode, out, ldo, c->dpart, in_lds);
+    hipLaunchKernelGGL((predict_rows_kernel<TS, T>), dim3((unsigned)blocks), dim3(128), lds, s, X, n, (const TS*)Q(c->Zs), M, c->D, c->kind,
+                       c->hyp, (const TS*)Q(c->Cf), K, V, (const T*)P(c->phi), ws, mode, out, ldo, c->dpart, in_lds);
     if (mode == 3) hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, blocks, 2, out_d);
     LAUNCHCHK("predict");
     return 0;
   }
 };
 
-#define DISPATCH(c, call_f32, call_f64) ((c)->dtype == GDRF_F32 ? (call_f32) : (call_f64))
 
 int gdrf_knm(gdrf_ctx* c, const void* X, int64_t n, const void* Z, const void* params, void* out, int64_t ldo, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH(c, Impl<float>::knm(c, (const float*)X, n, (const float*)Z, (const float*)params, (float*)out, ldo, s),
-                  Impl<double>::knm(c, (const double*)X, n, (const double*)Z, (const double*)params, (double*)out, ldo, s));
+  if (c->dtype == GDRF_F64) return Impl<double, double>::knm(c, (const double*)X, n, (const double*)Z, (const double*)params, (double*)out, ldo, s);
+  return Impl<float, float>::knm(c, (const float*)X, n, (const float*)Z, (const float*)params, (float*)out, ldo, s);
 }
 
 int gdrf_fill_eps(gdrf_ctx* c, uint64_t seed, uint32_t step, int64_t n_offset, int64_t n, void* eps, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((n + 255) / 256), c->K);
-  if (c->dtype == GDRF_F32) hipLaunchKernelGGL(fill_eps_kernel<float>, grid, dim3(256), 0, s, seed, step, n_offset, n, c->K, (float*)eps, n);
+  if (c->esz == 4) hipLaunchKernelGGL(fill_eps_kernel<float>, grid, dim3(256), 0, s, seed, step, n_offset, n, c->K, (float*)eps, n);
   else hipLaunchKernelGGL(fill_eps_kernel<double>, grid, dim3(256), 0, s, seed, step, n_offset, n, c->K, (double*)eps, n);
   LAUNCHCHK("fill_eps");
   return 0;
@@ -480,11 +524,23 @@ int gdrf_ll_const(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_host, v
   return 0;
 }
 
+#define TYPED3(c, fn, ...)                                                                                         \
+  do {                                                                                                             \
+    if ((c)->dtype == GDRF_F32) { using T = float; using I = Impl<float, double>; return I::fn(__VA_ARGS__); }     \
+    if ((c)->dtype == GDRF_F64) { using T = double; using I = Impl<double, double>; return I::fn(__VA_ARGS__); }   \
+    { using T = float; using I = Impl<float, float>; return I::fn(__VA_ARGS__); }                                  \
+  } while (0)
+
+int gdrf_probe(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t s = (hipStream_t)stream;
+  TYPED3(c, probe, c, (const T*)Z, (const T*)params, jitter, s);
+}
+
 int gdrf_factorize(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH(c, Impl<float>::prologue(c, (const float*)Z, (const float*)params, jitter, s),
-                  Impl<double>::prologue(c, (const double*)Z, (const double*)params, jitter, s));
+  TYPED3(c, factorize, c, (const T*)Z, (const T*)params, jitter, s);
 }
 
 int gdrf_step_local(gdrf_ctx* c, const void* X, const int32_t* ws, const void* eps, int64_t n, const void* Z, const void* params,
@@ -492,18 +548,14 @@ int gdrf_step_local(gdrf_ctx* c, const void* X, const int32_t* ws, const void* e
   HIPCHK(hipSetDevice(c->dev));
   if (n < 1 || n > c->ncap) return fail(-1, "gdrf_step_local", "n_local outside [1, n_cap]");
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH(c,
-      Impl<float>::step_local(c, (const float*)X, ws, (const float*)eps, n, (const float*)Z, (const float*)params, (float*)redT, redd, s),
-      Impl<double>::step_local(c, (const double*)X, ws, (const double*)eps, n, (const double*)Z, (const double*)params, (double*)redT, redd, s));
+  TYPED3(c, step_local, c, (const T*)X, ws, (const T*)eps, n, (const T*)Z, (const T*)params, (T*)redT, redd, s);
 }
 
 int gdrf_step_finish(gdrf_ctx* c, const void* Z, const void* params, const void* redT, const double* redd, double n_global,
                      double ll_const, void* grads, double* out_d, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH(c,
-      Impl<float>::step_finish(c, (const float*)Z, (const float*)params, (const float*)redT, redd, n_global, ll_const, (float*)grads, out_d, s),
-      Impl<double>::step_finish(c, (const double*)Z, (const double*)params, (const double*)redT, redd, n_global, ll_const, (double*)grads, out_d, s));
+  TYPED3(c, step_finish, c, (const T*)Z, (const T*)params, (const T*)redT, redd, n_global, ll_const, (T*)grads, out_d, s);
 }
 
 int gdrf_adam(gdrf_ctx* c, int mode, void* params, const void* grads, void* m, void* v, int64_t t, double lr, double b1, double b2,
@@ -514,7 +566,7 @@ int gdrf_adam(gdrf_ctx* c, int mode, void* params, const void* grads, void* m, v
   const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
   dim3 grid((unsigned)((n + 255) / 256));
   ScopedTimer tm(c, 14, s);
-  if (c->dtype == GDRF_F32)
+  if (c->esz == 4)
     hipLaunchKernelGGL(adam_kernel<float>, grid, dim3(256), 0, s, n, (float*)params, (const float*)grads, (float*)m, (float*)v, mode, lr,
                        b1, b2, eps, wd, clip, bc1, bc2, (const int*)c->flag);
   else
@@ -530,9 +582,7 @@ int gdrf_predict(gdrf_ctx* c, const void* X, int64_t n, const void* Z, const voi
   if (mode < 0 || mode > 3) return fail(-1, "gdrf_predict", "mode");
   if (mode == 3 && !ws) return fail(-1, "gdrf_predict", "perplexity needs ws");
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH(c,
-      Impl<float>::predict(c, (const float*)X, n, (const float*)Z, (const float*)params, ws, mode, (float*)out, out_d, s),
-      Impl<double>::predict(c, (const double*)X, n, (const double*)Z, (const double*)params, ws, mode, (double*)out, out_d, s));
+  TYPED3(c, predict, c, (const T*)X, n, (const T*)Z, (const T*)params, ws, mode, (T*)out, out_d, s);
 }
 
 int gdrf_chol_failed(gdrf_ctx* c, int* failed, void* stream) {

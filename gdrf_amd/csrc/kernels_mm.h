@@ -23,6 +23,13 @@ __global__ void prep_hyper_kernel(const T* __restrict__ params, Hyper* h) {
   }
 }
 
+// elementwise precision change (inducing points, all-reduced G^T) between the N-side and the solve precision
+template <typename TA, typename TB>
+__global__ void cast_kernel(int64_t n, const TA* __restrict__ in, TB* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (TB)in[i];
+}
+
 // K_uu[i][j] = k(z_i, z_j) + jitter * (i == j), zero outside M
 template <typename T>
 __global__ void kuu_kernel(const T* __restrict__ Z, int M, int Mp, int D, int kind, const Hyper* __restrict__ h,

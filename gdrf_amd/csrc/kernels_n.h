@@ -113,11 +113,13 @@ template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2,
 
 // (1) W = K_nm Linv^T : A generated on the fly (Z staged in LDS), Bt = Linv, triangular k range; stores W
 //     and the per-column-tile partial of q_n = ||w_n||^2
-template <typename T> struct FwdWProb : NTDefaultMap {
+// T = solve precision (f64 in the default fp32 mode: the triangular solve cancels terms ~|Linv||k| >> |w|),
+// TN = precision of the N-sized arrays (X in, W / qpart out)
+template <typename T, typename TN> struct FwdWProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
-  const T* X; int64_t nrows; const T* Z; int M, Mp, D, kind; const Hyper* h;
-  const T* Linv; T* W; T* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
+  const TN* X; int64_t nrows; const T* Z; int M, Mp, D, kind; const Hyper* h;
+  const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
   struct ACtx { T x[NTCfg<T>::VPT][GDRF_DMAX]; bool ok[NTCfg<T>::VPT]; T var, ils2; const T* Zs; };
   struct ECtx { T rs[4][4]; int ct; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
@@ -136,7 +138,7 @@ template <typename T> struct FwdWProb : NTDefaultMap {
       const int64_t r = m0 + nt_stage_row<T>(i);
       c.ok[i] = r < nrows;
 #pragma unroll
-      for (int d = 0; d < GDRF_DMAX; ++d) c.x[i][d] = (c.ok[i] && d < D) ? X[r * D + d] : T(0);
+      for (int d = 0; d < GDRF_DMAX; ++d) c.x[i][d] = (c.ok[i] && d < D) ? (T)X[r * D + d] : T(0);
     }
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
@@ -174,7 +176,7 @@ template <typename T> struct FwdWProb : NTDefaultMap {
         for (int b = 0; b < 4; ++b) {
           ec.rs[a][r] += acc[a][b][r] * acc[a][b][r];
           const int n = n0 + nt_acc_col(wc, b, lane);
-          if (m < nrows && n < Mp) W[m * Mp + n] = acc[a][b][r];
+          if (m < nrows && n < Mp) W[m * Mp + n] = (TN)acc[a][b][r];
         }
       }
   }
@@ -183,7 +185,7 @@ template <typename T> struct FwdWProb : NTDefaultMap {
     nt_rowsum_finish<T>(ec.rs, rsum, wr, wc, lane);
     if (threadIdx.x < GDRF_TILE) {
       const int64_t m = m0 + threadIdx.x;
-      if (m < nrows) qpart[(int64_t)ec.ct * ldq + m] = rsum[threadIdx.x];
+      if (m < nrows) qpart[(int64_t)ec.ct * ldq + m] = (TN)rsum[threadIdx.x];
     }
   }
 };
@@ -345,14 +347,14 @@ template <typename T> struct BwdWbarProb : NTXcdMap {
 };
 
 // (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
-template <typename T> struct BwdKnmProb : NTDefaultMap {
+template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
-  const T* Wbar; int64_t nrows; int M, Mp, D, kind;
+  const TN* Wbar; int64_t nrows; int M, Mp, D, kind;
   const T* LinvT;                  // [Mp][Mp], LinvT[i][j] = Linv[j][i]
-  const T* X; const T* Z; const Hyper* h;
+  const TN* X; const T* Z; const Hyper* h;
   double* part;                    // [gridDim.x][2]
-  struct ACtx { const T* p[NTCfg<T>::VPT]; };
+  struct ACtx { const TN* p[NTCfg<T>::VPT]; };
   struct ECtx { T s1, s2; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
@@ -367,7 +369,14 @@ template <typename T> struct BwdKnmProb : NTDefaultMap {
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const { e.s1 = 0; e.s2 = 0; }
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
-    return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
+    V v = vzero<T>();
+    if (c.p[i]) {
+      using VN = TN __attribute__((ext_vector_type(Vec16<T>::N)));      // same element count, N-side element type
+      const VN t = *reinterpret_cast<const VN*>(c.p[i] + k);
+#pragma unroll
+      for (int e = 0; e < Vec16<T>::N; ++e) v[e] = (T)t[e];
+    }
+    return v;
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int, int) const {
     const int c = n0 + nt_stage_row<T>(i);
@@ -391,7 +400,7 @@ template <typename T> struct BwdKnmProb : NTDefaultMap {
         if (m >= nrows) continue;
         T x[GDRF_DMAX];
 #pragma unroll
-        for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[m * D + d] : T(0);
+        for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? (T)X[m * D + d] : T(0);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int n = n0 + nt_acc_col(wc, b, lane);
@@ -683,8 +692,8 @@ __global__ void adam_kernel(int64_t n, T* __restrict__ p, const T* __restrict__ 
 // =====================================================================================
 // predictive path (mean only): loc_kn = k(x_n, Z) c_k,  c_k = Linv^T u_k
 // =====================================================================================
-template <typename T>
-__global__ void predict_coeff_kernel(const T* __restrict__ Linv, const T* __restrict__ U, int M, int Mp, int K, T* __restrict__ Cf) {
+template <typename T, typename TN>
+__global__ void predict_coeff_kernel(const T* __restrict__ Linv, const TN* __restrict__ U, int M, int Mp, int K, T* __restrict__ Cf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
   if (i >= M) return;
   double s = 0;
@@ -693,11 +702,11 @@ __global__ void predict_coeff_kernel(const T* __restrict__ Linv, const T* __rest
 }
 
 // mode 0: write loc (K,N) ; 1: topic_probs (N,K) ; 2: word_probs (N,V) ; 3: perplexity partial sums
-template <typename T>
-__global__ __launch_bounds__(128) void predict_rows_kernel(const T* __restrict__ X, int64_t nrows, const T* __restrict__ Z, int M, int D,
+template <typename T, typename TN>
+__global__ __launch_bounds__(128) void predict_rows_kernel(const TN* __restrict__ X, int64_t nrows, const T* __restrict__ Z, int M, int D,
                                                            int kind, const Hyper* __restrict__ h, const T* __restrict__ Cf, int K, int V,
-                                                           const T* __restrict__ phi, const int32_t* __restrict__ ws, int mode,
-                                                           T* __restrict__ out, int64_t ldo, double* __restrict__ dpart,
+                                                           const TN* __restrict__ phi, const int32_t* __restrict__ ws, int mode,
+                                                           TN* __restrict__ out, int64_t ldo, double* __restrict__ dpart,
                                                            int cf_in_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* scratch = reinterpret_cast<double*>(smem);       // [16]
@@ -707,14 +716,14 @@ __global__ __launch_bounds__(128) void predict_rows_kernel(const T* __restrict__
   const T* Cs = cf_in_lds ? CsL : Cf;
   for (int e = threadIdx.x; e < M * D; e += blockDim.x) Zs[e] = Z[e];
   if (cf_in_lds) for (int e = threadIdx.x; e < K * M; e += blockDim.x) CsL[e] = Cf[e];
-  if (mode >= 2) for (int e = threadIdx.x; e < K * V; e += blockDim.x) phiS[e] = phi[e];
+  if (mode >= 2) for (int e = threadIdx.x; e < K * V; e += blockDim.x) phiS[e] = (T)phi[e];
   __syncthreads();
   const T var = (T)h->var, ils2 = (T)h->inv_ls2;
   double s_wlp = 0, s_w = 0;
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < nrows; n += (int64_t)gridDim.x * blockDim.x) {
     T x[GDRF_DMAX];
 #pragma unroll
-    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[n * D + d] : T(0);
+    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? (T)X[n * D + d] : T(0);
     T lc[GDRF_KMAX];
 #pragma unroll
     for (int k = 0; k < GDRF_KMAX; ++k) lc[k] = 0;
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(128) void predict_rows_kernel(const T* __restrict__
     }
     if (mode == 0) {
 #pragma unroll
-      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) out[(int64_t)k * ldo + n] = lc[k];
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) out[(int64_t)k * ldo + n] = (TN)lc[k];
       continue;
     }
     T mx = -3.0e38f;
@@ -742,14 +751,14 @@ __global__ __launch_bounds__(128) void predict_rows_kernel(const T* __restrict__
     for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) lc[k] *= ise;
     if (mode == 1) {
 #pragma unroll
-      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) out[n * ldo + k] = lc[k];
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) out[n * ldo + k] = (TN)lc[k];
       continue;
     }
     for (int v = 0; v < V; ++v) {
       T p = 0;
 #pragma unroll
       for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) p += lc[k] * phiS[k * V + v];
-      if (mode == 2) out[n * ldo + v] = p;
+      if (mode == 2) out[n * ldo + v] = (TN)p;
       else { const double w = (double)ws[n * V + v]; s_wlp += w * (double)t_log<T>(p); s_w += w; }
     }
   }

@@ -32,7 +32,7 @@ class Engine:
     """One device context for fixed (n_cap, M, K, V, D, dtype, kernel)."""
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
-                 device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto"):
+                 device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -51,7 +51,9 @@ class Engine:
         torch.cuda.set_device(dev_index)
         ctx = C.c_void_p()
         _lib.check(self.lib.gdrf_ctx_create(C.byref(ctx), dev_index, self.n_cap, self.M, self.K, self.V, self.D,
-                                            0 if dtype == torch.float32 else 1, KERNEL_IDS[kernel]), "gdrf_ctx_create")
+                                            (2 if pure_fp32 else 0) if dtype == torch.float32 else 1, KERNEL_IDS[kernel]),
+                   "gdrf_ctx_create")
+        self.pure_fp32 = bool(pure_fp32) and dtype == torch.float32
         self.ctx = ctx
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
@@ -117,7 +119,8 @@ class Engine:
         """Copy of a workspace buffer in its natural (unpadded) shape."""
         ptr, cnt = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.gdrf_ws_ptr(self.ctx, _WS_IDS[name], C.byref(ptr), C.byref(cnt)), "gdrf_ws_ptr")
-        flat = torch.empty(cnt.value, dtype=self.dtype, device=self.device)
+        esz = self.lib.gdrf_ws_elem_size(self.ctx, _WS_IDS[name])
+        flat = torch.empty(cnt.value, dtype=torch.float32 if esz == 4 else torch.float64, device=self.device)
         _lib.check(self.lib.gdrf_ws_copy(self.ctx, _WS_IDS[name], flat.data_ptr(), cnt.value, _stream_ptr(self.device)),
                    "gdrf_ws_copy")
         torch.cuda.synchronize(self.device)
@@ -138,8 +141,8 @@ class Engine:
             return flat.view(self.K, self.V).clone()
         raise KeyError(name)
 
-    TIMING_SLOTS = ("factorize", "k_nm", "transforms", "fwd_w", "loc", "fwd_t", "elbo_rows", "bwd_wbar", "bwd_knm",
-                    "tn_sym", "tn_gt", "slab_reduce", "ubar", "step_finish", "adam")
+    TIMING_SLOTS = ("probe", "k_nm", "transforms", "fwd_w", "loc", "fwd_t", "elbo_rows", "bwd_wbar", "bwd_knm",
+                    "tn_sym", "tn_gt", "slab_reduce", "ubar", "step_finish", "adam", "factorize")
 
     def set_timing(self, enable: bool):
         _lib.check(self.lib.gdrf_set_timing(self.ctx, 1 if enable else 0), "gdrf_set_timing")
@@ -190,14 +193,21 @@ class Engine:
         return sum(self.jitter * (10 ** n) for n in range(level + 1))
 
     def factorize(self, force_level: Optional[int] = None) -> int:
-        """jittercholesky: smallest level whose cumulative jitter gives a positive-definite K_uu
-        (every call starts from level 0, as the reference rebuilds K_uu each time)."""
+        """jittercholesky: smallest level whose cumulative jitter lets the Cholesky factorisation succeed IN THE
+        ARRAY PRECISION (every call starts from level 0, as the reference rebuilds K_uu each time), then the
+        factor and its inverse in the solve precision at that level."""
         s = _stream_ptr(self.device)
         failed = C.c_int()
         level = 0 if force_level is None else force_level
         while level < self.maxjitter:
-            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(level), s),
-                       "gdrf_factorize")
+            jt = self.jitter_total(level)
+            if force_level is None:
+                _lib.check(self.lib.gdrf_probe(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jt, s), "gdrf_probe")
+                _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), s), "gdrf_chol_failed")
+                if failed.value:
+                    level += 1
+                    continue
+            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jt, s), "gdrf_factorize")
             _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), s), "gdrf_chol_failed")
             if not failed.value:
                 self.last_jitter_level = level

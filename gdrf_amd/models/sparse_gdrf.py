@@ -88,6 +88,7 @@ class SparseMultinomialGDRF:
         randomize_metric=None,
         randomize_iters: int = 100,
         dtype: torch.dtype = torch.float32,
+        pure_fp32: bool = False,
         inducing_points: Optional[torch.Tensor] = None,
         seed: Optional[int] = None,
         **kwargs,
@@ -110,6 +111,7 @@ class SparseMultinomialGDRF:
         self._n_dims = len(self._world)
         self.device = torch.device(device)
         self.dtype = dtype
+        self._pure_fp32 = bool(pure_fp32)
         self._kernel = kernel
         if kernel.input_dim != self._n_dims:
             raise ValueError("kernel.input_dim does not match the world's dimensionality")
@@ -155,7 +157,7 @@ class SparseMultinomialGDRF:
         if e is not None and n <= e.n_cap:
             return e
         new = Engine(n, self.M, self._K, self._V, self.D, dtype=self.dtype, kernel=self._kernel.name, device=self.device,
-                     jitter=self._jitter, maxjitter=self._maxjitter)
+                     jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32)
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
         if e is None:
@@ -179,7 +181,7 @@ class SparseMultinomialGDRF:
                 ret = torch.softmax(torch.randn(ret.shape, generator=self._gen, dtype=torch.float64), dim=-2)
             eng.view("phi_unc").copy_(ret.log().to(eng.dtype))            # simplex transform inverse
             eng.factorize()                                               # u_scale_tril = jittercholesky(kernel(Z)) x K
-            L = eng.workspace("L")
+            L = eng.workspace("L").to(eng.dtype)
             unc = L.tril(-1) + torch.diag(L.diagonal().log())             # lower_cholesky transform inverse
             eng.view("u_scale_tril_unc").copy_(unc.unsqueeze(0).expand(self._K, -1, -1))
 

@@ -8,8 +8,13 @@
  * Conventions: every function returns 0 on success, < 0 on a HIP/argument error (message from
  * gdrf_last_error()); pointers named *_dev are borrowed device pointers that the caller keeps
  * alive until the stream has been synchronised; `stream` is a hipStream_t passed as void*;
- * no exceptions cross the ABI; one host thread per context.  dtype: 0 = f32, 1 = f64 (the
- * element type of every "void*" real array below).  kernel_id: 0 = RBF, 1 = Matern52.
+ * no exceptions cross the ABI; one host thread per context.  kernel_id: 0 = RBF, 1 = Matern52.
+ * dtype fixes the element type of every "void*" real array below:
+ *   GDRF_F32 (0)      float arrays.  The K-fold contractions run on f32 MFMA; the ill-conditioned pieces (K_uu, its
+ *                     Cholesky factor and inverse, the solve W = K_nm L^-T, its backward and the M x M epilogue) run
+ *                     in f64, because the fp32 solve cancels terms |L^-1||k| >> |w| (DESIGN.md "precision").
+ *   GDRF_F64 (1)      double arrays, everything f64.
+ *   GDRF_F32_PURE (2) float arrays, everything f32 (the reference's literal .float() arithmetic; for A/B runs).
  */
 #ifndef GDRF_HIP_H
 #define GDRF_HIP_H
@@ -20,7 +25,7 @@ extern "C" {
 
 typedef struct gdrf_ctx gdrf_ctx;
 
-enum { GDRF_F32 = 0, GDRF_F64 = 1 };
+enum { GDRF_F32 = 0, GDRF_F64 = 1, GDRF_F32_PURE = 2 };
 enum { GDRF_RBF = 0, GDRF_MATERN52 = 1 };
 enum { GDRF_ADAM = 0, GDRF_ADAMW = 1, GDRF_CLIPPED_ADAM = 2 };
 enum { GDRF_PRED_LOC = 0, GDRF_PRED_TOPIC_PROBS = 1, GDRF_PRED_WORD_PROBS = 2, GDRF_PRED_PERPLEXITY = 3 };
@@ -55,10 +60,14 @@ int gdrf_fill_eps(gdrf_ctx* ctx, uint64_t seed, uint32_t step, int64_t n_offset,
  * (gdrf/models/sparse_gdrf.py:363-372).  Synchronises the stream. */
 int gdrf_ll_const(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* out_host, void* stream);
 
-/* K_uu = k(Z,Z) + jitter_total*I, its Cholesky factor L and L^{-1}, kept in the context for the
- * calls below: one attempt of jittercholesky (gdrf/models/utils.py:27-40) on
- * kernel(inducing_points) (gdrf/models/sparse_gdrf.py:327-328,382-383).  A non-positive pivot is
- * reported by gdrf_chol_failed(); the host then retries with the next cumulative jitter. */
+/* One attempt of jittercholesky (gdrf/models/utils.py:27-40) on kernel(inducing_points) + jitter_total*I
+ * (gdrf/models/sparse_gdrf.py:327-328,382-383) in the array precision -- the precision in which the reference's
+ * torch.linalg.cholesky decides whether more jitter is needed.  A non-positive pivot is reported by
+ * gdrf_chol_failed(); the host then retries with the next cumulative jitter. */
+int gdrf_probe(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream);
+
+/* K_uu + jitter_total*I, its Cholesky factor L and L^{-1} in the solve precision, kept in the context for
+ * the calls below (reuses the probe's factor when both precisions coincide). */
 int gdrf_factorize(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream);
 
 /* Forward + backward over this rank's n_local observations: everything of one
@@ -92,12 +101,14 @@ int gdrf_chol_failed(gdrf_ctx* ctx, int* failed_host, void* stream);
 /* Borrowed pointers into the workspace (for parity tests): which = 0 W, 1 Wbar, 2 q, 3 loc, 4 tt,
  * 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST. */
 int gdrf_ws_ptr(gdrf_ctx* ctx, int which, void** ptr, int64_t* nelem);
+/* Element size (4 or 8 bytes) of that buffer: Kuu, L, Linv, LinvT live in the solve precision. */
+int gdrf_ws_elem_size(gdrf_ctx* ctx, int which);
 /* Device-to-device copy of the first nelem elements of that buffer into dst_dev. */
 int gdrf_ws_copy(gdrf_ctx* ctx, int which, void* dst_dev, int64_t nelem, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).  Slots:
  * 0 factorize, 1 k_nm, 2 transforms+B_k, 3 fwd_w, 4 loc (W U^T), 5 fwd_t, 6 elbo_rows, 7 bwd_wbar,
- * 8 bwd_knm, 9 tn_sym (A_k), 10 tn_gt, 11 slab reductions, 12 ubar, 13 step_finish, 14 adam.
+ * 8 bwd_knm, 9 tn_sym (A_k), 10 tn_gt, 11 slab reductions, 12 ubar, 13 step_finish, 14 adam, 15 factorize (slot 0 = probes).
  * gdrf_get_timing synchronises on the recorded events and returns accumulated ms and counts. */
 int gdrf_set_timing(gdrf_ctx* ctx, int enable);
 int gdrf_get_timing(gdrf_ctx* ctx, double* ms_out, int64_t* count_out, int nslots);
