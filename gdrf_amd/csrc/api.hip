@@ -46,6 +46,7 @@ struct gdrf_ctx {
   int nsplit_cap;
   // solve precision, M x M (ld Mp)
   void *Kuu, *Lw, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *Zs, *GTs;
+  void *Knm;                  // [ncap][Mp] K_nm in the solve precision (forward A operand, backward epilogue)
   // probe (N-side precision) scratch, only when T != TS
   void *pK, *pL;
   double probe_jitter; int probe_ok;
@@ -151,6 +152,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->ssz)
   AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
   AL(c->Cf, (size_t)K * M * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
+  AL(c->Knm, (size_t)n_cap * c->Mp * c->ssz)
   if (c->esz != c->ssz) { AL(c->pK, mm) AL(c->pL, mm) }
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
   AL(c->phi, (size_t)K * V * c->esz)
@@ -269,7 +271,7 @@ template <typename T, typename TS> struct Impl {
   template <typename E>
   static int mm_nt(gdrf_ctx* c, const E* A, int64_t abs_, const E* Bt, int64_t bbs, E* Cm, int64_t cbs, E alpha, int batch,
                    hipStream_t s) {
-    MMProb<E> p{{}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
+    MMProb<E> p{{}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
     dim3 grid(c->nt * c->nt, batch);
     hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");
@@ -325,8 +327,22 @@ template <typename T, typename TS> struct Impl {
     int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(knm_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D, c->kind, c->hyp, out, ldo);
+    hipLaunchKernelGGL((knm_kernel<T, T, true>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D, c->kind, c->hyp, out, ldo);
     LAUNCHCHK("knm");
+    return 0;
+  }
+
+  // K_nm in the solve precision with the exact exponential, zero-padded to Mp columns
+  static int knm_solve(gdrf_ctx* c, const T* X, int64_t n, hipStream_t s) {
+    ScopedTimer tm(c, 1, s);
+    const int VE = Vec16<TS>::N;
+    const int vpr = (c->Mp + VE - 1) / VE, rpp = vpr <= 256 ? 256 / vpr : 1;
+    int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((knm_kernel<TS, T, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, (const TS*)Q(c->Zs), c->M, c->D, c->kind,
+                       c->hyp, Q(c->Knm), (int64_t)c->Mp);
+    LAUNCHCHK("knm_solve");
     return 0;
   }
 
@@ -349,23 +365,21 @@ template <typename T, typename TS> struct Impl {
     const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
     // (1) W = Knm Linv^T in the solve precision, stored in the N-side precision
     {
+      if ((rc = knm_solve(c, X, n, s))) return rc;
       ScopedTimer tm(c, 3, s);
-      FwdWProb<TS, T> p{{}, X, n, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
-      const size_t lds = CS::LDS_BYTES + (size_t)Mp * c->D * sizeof(TS);
-      if (lds > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TS, FwdWProb<TS, T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), lds, s, p);
+      FwdWProb<TS, T> p{{}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
+      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), CS::LDS_BYTES, s, p);
     }
     // loc = W U^T
     {
       ScopedTimer tm(c, 4, s);
-      LocProb<T> p{{}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
+      LocProb<T> p{{}, {}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, s, p);
     }
     // (2) tt_kn = ||S_k^T w_n||^2
     {
       ScopedTimer tm(c, 5, s);
-      FwdTProb<T> p{{}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
+      FwdTProb<T> p{{}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
     }
     LAUNCHCHK("forward");
@@ -391,7 +405,7 @@ template <typename T, typename TS> struct Impl {
     // (3) Wbar
     {
       ScopedTimer tm(c, 7, s);
-      BwdWbarProb<T> p{{}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
+      BwdWbarProb<T> p{{}, {}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
       const size_t lds = C::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(T);
       if (lds > 48 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -400,7 +414,8 @@ template <typename T, typename TS> struct Impl {
     // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
       ScopedTimer tm(c, 8, s);
-      BwdKnmProb<TS, T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), X, (const TS*)Q(c->Zs), c->hyp, c->dpart};
+      BwdKnmProb<TS, T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
+                          c->dpart};
       const int64_t nb = rtiles * c->nt;
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
       hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);

@@ -86,6 +86,13 @@ template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T 
   const T a = T(2.23606797749978969641) * r;
   return var * t_exp<T>(-a) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
 }
+// the same derivative from an already evaluated k (no second exponential): exp(-a) = k / (var (1 + a + 5/3 r^2))
+template <typename T> __device__ __forceinline__ T dcov_dlogls_from_k(int kind, T k, T r2) {
+  if (kind == 0) return k * r2;
+  const T r = t_sqrt<T>(r2 + T(1e-12));
+  const T a = T(2.23606797749978969641) * r;
+  return k / (T(1) + a + (T(5) / T(3)) * r * r) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
+}
 template <typename T> __device__ __forceinline__ T sqdist(const T* __restrict__ x, const T* __restrict__ z, int D) {
   T s = 0;
   for (int d = 0; d < D; ++d) { const T t = x[d] - z[d]; s += t * t; }

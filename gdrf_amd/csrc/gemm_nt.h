@@ -15,7 +15,9 @@
 //   int  a_reuse()
 //   int  extra_lds_bytes()                problem-owned LDS behind the two staging tiles
 //   void krange(m0, n0, bz, kb, ke)       A-column range [kb, ke), multiples of BK (triangular skipping)
-//   void prepA(actx, m0, bz, extra) ; V loadA(actx, i, k, bz)     i = 0..VPT-1: the thread's i-th staged row
+//   void prepA(actx, m0, bz, extra) ; AVec loadA(actx, i, k, bz)  i = 0..VPT-1: the thread's i-th staged row
+//   V    a_to_lds(AVec)                   conversion applied when the prefetched registers are written to LDS (so that a
+//                                         precision change does not force a wait on the loads ahead of the MFMAs)
 //   V    loadB(n0, i, k, rep, bz)
 //   void prepE(ectx, m0, bz)
 //   void tile_done(acc, m0, n0, bz, ectx, wr, wc, lane)
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
     int kb, ke;
     p.krange(m0, n0, bz, kb, ke);
     const int nchunks = (ke > kb) ? ((ke - kb) / C::BK) * R : 0;
-    V ra[C::VPT], rb[C::VPT];
+    typename P::AVec ra[C::VPT];
+    V rb[C::VPT];
     if (nchunks > 0) {
 #pragma unroll
       for (int i = 0; i < C::VPT; ++i) { ra[i] = p.loadA(actx, i, kb + srow_k, bz); rb[i] = p.loadB(n0, i, kb + srow_k, 0, bz); }
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
 #pragma unroll
       for (int i = 0; i < C::VPT; ++i) {
         const int r = nt_stage_row<T>(i);
-        if (rep == 0) *reinterpret_cast<V*>(&As[r * C::LDK + srow_k]) = ra[i];
+        if (rep == 0) *reinterpret_cast<V*>(&As[r * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
         *reinterpret_cast<V*>(&Bs[r * C::LDK + srow_k]) = rb[i];
       }
       __syncthreads();
@@ -144,6 +147,12 @@ template <typename T> __device__ __forceinline__ int nt_acc_row(int wr, int a, i
 __device__ __forceinline__ int nt_acc_col(int wc, int b, int lane) { return wc * 64 + b * 16 + (lane & 15); }
 
 // default block -> (row tile, column tile) map: column tile fastest
+// default staging: the prefetched A registers already hold the LDS representation
+template <typename T> struct NTPlainA {
+  using AVec = typename Vec16<T>::type;
+  __device__ __forceinline__ AVec a_to_lds(const AVec& v) const { return v; }
+};
+
 struct NTDefaultMap {
   __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
     if (loopc) { rtile = bid; ct = 0; } else { rtile = bid / nct; ct = (int)(bid % nct); }

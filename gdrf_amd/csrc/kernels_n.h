@@ -26,13 +26,15 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type vzero()
 // =====================================================================================
 template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var);
 
-template <typename T>
-__global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64_t N, const T* __restrict__ Z, int M, int D,
+// T: output / arithmetic type, TX: type of X, FAST: v_exp_f32-based exponential (roofline kernel) or exact exp
+// (the solve-precision copy of K_nm that feeds W = K_nm L^-T).  Columns M..ldo-1 of every row are written as zeros.
+template <typename T, typename TX, bool FAST>
+__global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int64_t N, const T* __restrict__ Z, int M, int D,
                                                   int kind, const Hyper* __restrict__ h, T* __restrict__ out, int64_t ldo) {
   using V = typename Vec16<T>::type;
   constexpr int VE = Vec16<T>::N;
   const T var = (T)h->var, ils2 = (T)h->inv_ls2;
-  const int vpr = (M + VE - 1) / VE;                   // 16-byte vectors per output row
+  const int vpr = (int)((ldo + VE - 1) / VE);          // 16-byte vectors per output row (ldo >= M)
   const bool aligned = (ldo % VE) == 0;
   if (vpr <= 256) {
     // fast path: a thread owns ONE column vector for the whole launch, so its VE inducing points live in
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64
       for (int u = 0; u < 4; ++u) {
         const int64_t row = row0 + u * stride;
 #pragma unroll
-        for (int d = 0; d < GDRF_DMAX; ++d) x[u][d] = (row < N && d < D) ? X[row * D + d] : T(0);
+        for (int d = 0; d < GDRF_DMAX; ++d) x[u][d] = (row < N && d < D) ? (T)X[row * D + d] : T(0);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64
           T r2 = 0;
 #pragma unroll
           for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[u][d] - z[e][d]; r2 += t * t; }
-          o[e] = (i0 + e < M) ? cov_fast<T>(kind, r2 * ils2, var) : T(0);
+          o[e] = (i0 + e < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var) : cov_from_r2<T>(kind, r2 * ils2, var)) : T(0);
         }
         T* orow = out + row * ldo;
         if (vec_ok) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0));
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64
   for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
     T x[GDRF_DMAX];
 #pragma unroll
-    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? X[row * D + d] : T(0);
+    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? (T)X[row * D + d] : T(0);
     T* orow = out + row * ldo;
     for (int cv = threadIdx.x; cv < vpr; cv += 256) {
       const int i0 = cv * VE;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const T* __restrict__ X, int64
 #pragma unroll
           for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Z[(int64_t)i * D + d]; r2 += t * t; }
         }
-        o[e] = (i < M) ? cov_fast<T>(kind, r2 * ils2, var) : T(0);
+        o[e] = (i < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var) : cov_from_r2<T>(kind, r2 * ils2, var)) : T(0);
       }
       if (aligned && i0 + VE <= ldo) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0));
       else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) orow[i0 + e] = o[e];
@@ -111,16 +113,16 @@ template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2,
   return var * (1.0f + a + (5.0f / 3.0f) * r * r) * __expf(-a);
 }
 
-// (1) W = K_nm Linv^T : A generated on the fly (Z staged in LDS), Bt = Linv, triangular k range; stores W
-//     and the per-column-tile partial of q_n = ||w_n||^2
+// (1) W = K_nm Linv^T : A = the solve-precision copy of K_nm (knm_kernel), Bt = Linv, triangular k range;
+//     stores W and the per-column-tile partial of q_n = ||w_n||^2.
 // T = solve precision (f64 in the default fp32 mode: the triangular solve cancels terms ~|Linv||k| >> |w|),
-// TN = precision of the N-sized arrays (X in, W / qpart out)
-template <typename T, typename TN> struct FwdWProb : NTDefaultMap {
+// TN = precision of the N-sized outputs (W, qpart)
+template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
-  const TN* X; int64_t nrows; const T* Z; int M, Mp, D, kind; const Hyper* h;
+  const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
-  struct ACtx { T x[NTCfg<T>::VPT][GDRF_DMAX]; bool ok[NTCfg<T>::VPT]; T var, ils2; const T* Zs; };
+  struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx { T rs[4][4]; int ct; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
@@ -128,17 +130,11 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap {
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const {
     kb = 0; ke = n0 + GDRF_TILE; if (ke > Mp) ke = Mp;
   }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char* extra) const {
-    T* Zs = reinterpret_cast<T*>(extra);                 // [Mp][D], zero rows beyond M
-    for (int e = threadIdx.x; e < Mp * D; e += 256) Zs[e] = (e < M * D) ? Z[e] : T(0);
-    __syncthreads();
-    c.Zs = Zs; c.var = (T)h->var; c.ils2 = (T)h->inv_ls2;
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const {
 #pragma unroll
     for (int i = 0; i < NTCfg<T>::VPT; ++i) {
       const int64_t r = m0 + nt_stage_row<T>(i);
-      c.ok[i] = r < nrows;
-#pragma unroll
-      for (int d = 0; d < GDRF_DMAX; ++d) c.x[i][d] = (c.ok[i] && d < D) ? (T)X[r * D + d] : T(0);
+      c.p[i] = (r < nrows) ? Knm + r * Mp : nullptr;
     }
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
@@ -149,16 +145,7 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap {
     e.ct = 0;
   }
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
-    V o;
-#pragma unroll
-    for (int e = 0; e < Vec16<T>::N; ++e) {
-      const int idx = k + e;
-      T r2 = 0;
-#pragma unroll
-      for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = c.x[i][d] - c.Zs[idx * D + d]; r2 += t * t; }
-      o[e] = (c.ok[i] && idx < M) ? cov_fast<T>(kind, r2 * c.ils2, c.var) : T(0);
-    }
-    return o;
+    return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int, int) const {
     const int c = n0 + nt_stage_row<T>(i);
@@ -191,7 +178,7 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap {
 };
 
 // (1b) loc = W U^T on the matrix cores: Bt = zero-padded u_loc [128][Mp]; stores loc[k][n] for k < K
-template <typename T> struct LocProb : NTDefaultMap {
+template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   const T* W; int64_t nrows; int Mp, K;
@@ -235,7 +222,7 @@ template <typename T> struct LocProb : NTDefaultMap {
 };
 
 // (2) T_k = W S_k (never stored) -> tt[k][n] = sum_j T_k[n][j]^2 ; one workgroup walks all column tiles
-template <typename T> struct FwdTProb : NTDefaultMap {
+template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   const T* W; int64_t nrows; int Mp;
@@ -288,7 +275,7 @@ template <typename T> struct FwdTProb : NTDefaultMap {
 
 // (3) Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W.  One staged chunk of W serves all K
 //     topics (a_reuse = K): the per-(topic,row) factor 2 vbar_kn sits in an LDS table and scales the A fragments.
-template <typename T> struct BwdWbarProb : NTXcdMap {
+template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = true;
   const T* W; int64_t nrows; int M, Mp, K;
@@ -352,6 +339,7 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
   static constexpr bool SCALE_A = false;
   const TN* Wbar; int64_t nrows; int M, Mp, D, kind;
   const T* LinvT;                  // [Mp][Mp], LinvT[i][j] = Linv[j][i]
+  const T* Knm;                    // [nrows][Mp] solve-precision K_nm (same buffer the forward consumed)
   const TN* X; const T* Z; const Hyper* h;
   double* part;                    // [gridDim.x][2]
   struct ACtx { const TN* p[NTCfg<T>::VPT]; };
@@ -368,14 +356,18 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
     }
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const { e.s1 = 0; e.s2 = 0; }
-  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
-    V v = vzero<T>();
-    if (c.p[i]) {
-      using VN = TN __attribute__((ext_vector_type(Vec16<T>::N)));      // same element count, N-side element type
-      const VN t = *reinterpret_cast<const VN*>(c.p[i] + k);
+  using AVec = TN __attribute__((ext_vector_type(Vec16<T>::N)));        // same element count, N-side element type
+  __device__ __forceinline__ AVec loadA(const ACtx& c, int i, int k, int) const {
+    AVec t;
 #pragma unroll
-      for (int e = 0; e < Vec16<T>::N; ++e) v[e] = (T)t[e];
-    }
+    for (int e = 0; e < Vec16<T>::N; ++e) t[e] = 0;
+    if (c.p[i]) t = *reinterpret_cast<const AVec*>(c.p[i] + k);
+    return t;
+  }
+  __device__ __forceinline__ V a_to_lds(const AVec& t) const {
+    V v;
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) v[e] = (T)t[e];
     return v;
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int, int) const {
@@ -384,7 +376,7 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
   }
   template <class Acc>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
-    const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+    const T ils2 = (T)h->inv_ls2;
     T z[4][GDRF_DMAX];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -409,9 +401,9 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
 #pragma unroll
           for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - z[b][d]; r2 += t * t; }
           r2 *= ils2;
-          const T kv = cov_fast<T>(kind, r2, var);
+          const T kv = Knm[m * Mp + n];
           e.s1 += acc[a][b][r] * kv;
-          e.s2 += acc[a][b][r] * dcov_dlogls<T>(kind, kv, r2, var);
+          e.s2 += acc[a][b][r] * dcov_dlogls_from_k<T>(kind, kv, r2);
         }
       }
   }
