@@ -156,7 +156,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   if (c->esz != c->ssz) { AL(c->pK, mm) AL(c->pL, mm) }
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
   AL(c->phi, (size_t)K * V * c->esz)
-  AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)c->nt * c->ldk * c->esz)
+  AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)((c->Mp + 63) / 64) * c->ldk * c->esz)
   AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
   AL(c->q, (size_t)c->ldk * c->esz) AL(c->asum, (size_t)c->ldk * c->esz)
   AL(c->loc, (size_t)K * c->ldk * c->esz) AL(c->tt, (size_t)K * c->ldk * c->esz) AL(c->vbar, (size_t)K * c->ldk * c->esz)
@@ -168,7 +168,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   c->erows_grid_cap = 1024;
   AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
   const int64_t rtiles = (n_cap + GDRF_TILE - 1) / GDRF_TILE;
-  c->dpart_len = std::max<int64_t>((rtiles * c->nt + 16) * 2, 8192);
+  c->dpart_len = std::max<int64_t>((rtiles * ((c->Mp + 63) / 64) + 16) * 2, 8192);
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
@@ -268,11 +268,14 @@ template <typename T, typename TS> struct Impl {
   static const T* P(const void* p) { return reinterpret_cast<const T*>(p); }
   static TS* Q(void* p) { return reinterpret_cast<TS*>(p); }
 
+  // column tiles of the NT core for element type E (128 wide for f32, 64 for f64); row tiles are always 128
+  template <typename E> static int nct(const gdrf_ctx* c) { return (c->Mp + NTCfg<E>::CW - 1) / NTCfg<E>::CW; }
+
   template <typename E>
   static int mm_nt(gdrf_ctx* c, const E* A, int64_t abs_, const E* Bt, int64_t bbs, E* Cm, int64_t cbs, E alpha, int batch,
                    hipStream_t s) {
     MMProb<E> p{{}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
-    dim3 grid(c->nt * c->nt, batch);
+    dim3 grid(c->nt * nct<E>(c), batch);
     hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");
     return 0;
@@ -368,7 +371,7 @@ template <typename T, typename TS> struct Impl {
       if ((rc = knm_solve(c, X, n, s))) return rc;
       ScopedTimer tm(c, 3, s);
       FwdWProb<TS, T> p{{}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
-      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * c->nt)), dim3(256), CS::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
     }
     // loc = W U^T
     {
@@ -395,7 +398,7 @@ template <typename T, typename TS> struct Impl {
         HIPCHK(hipFuncSetAttribute((const void*)elbo_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t nblk = (n + RB - 1) / RB;
       egrid = (int)std::min<int64_t>(nblk, c->erows_grid_cap);
-      hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), c->nt, P(c->loc), P(c->tt), eps,
+      hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
                          ldk, n, ws, P(c->phi), P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
       LAUNCHCHK("elbo_rows");
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
@@ -409,14 +412,14 @@ template <typename T, typename TS> struct Impl {
       const size_t lds = C::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(T);
       if (lds > 48 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)round_up(rtiles * c->nt, 8)), dim3(256), lds, s, p);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)round_up(rtiles * nct<T>(c), 8)), dim3(256), lds, s, p);
     }
     // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
       ScopedTimer tm(c, 8, s);
       BwdKnmProb<TS, T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
                           c->dpart};
-      const int64_t nb = rtiles * c->nt;
+      const int64_t nb = rtiles * nct<TS>(c);
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
       hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 2, redd + 4);

@@ -33,8 +33,14 @@ template <typename T> struct NTCfg {
   static constexpr int LDK = BK + VE;                       // padded LDS row: 144 bytes
   static constexpr int KG = BK / 4;                         // k indices per lane group per chunk
   static constexpr int VPR = BK / VE;                       // 8 vectors per staged row
-  static constexpr int VPT = GDRF_TILE * VPR / 256;         // 4 vectors per thread per operand
-  static constexpr int LDS_BYTES = 2 * GDRF_TILE * LDK * (int)sizeof(T);
+  static constexpr int VPT = GDRF_TILE * VPR / 256;         // 4 vectors per thread for the A tile (128 rows)
+  // column-tile width: 128 for f32; 64 for f64, whose accumulators are twice as wide -- the narrower tile keeps a
+  // workgroup at 64 accumulator registers per lane so that 2-3 workgroups share a CU and hide each other's
+  // staging / epilogue phases (at 128 the f64 kernels fit one wave per SIMD and ran at ~35-58 % of the f64 MFMA peak)
+  static constexpr int CW = sizeof(T) == 4 ? 128 : 64;
+  static constexpr int NB = CW / 32;                        // 16-wide MFMA column tiles per wave
+  static constexpr int VPTB = CW * VPR / 256;               // vectors per thread for the B tile (CW rows)
+  static constexpr int LDS_BYTES = (GDRF_TILE + CW) * LDK * (int)sizeof(T);
 };
 
 // row (0..127) and k offset (elements) of the i-th vector a thread stages
@@ -42,7 +48,7 @@ template <typename T> __device__ __forceinline__ int nt_stage_row(int i) { retur
 template <typename T> __device__ __forceinline__ int nt_stage_k() { return (threadIdx.x & 7) * NTCfg<T>::VE; }
 
 template <typename T, class P>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(P p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
   using C = NTCfg<T>;
   using V = typename Vec16<T>::type;
   using MM = Mfma<T>;
@@ -71,40 +77,43 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
 
   const int srow_k = nt_stage_k<T>();
   for (int ct = ct_first; ct < ct_last; ++ct) {
-    const int n0 = ct * GDRF_TILE;
-    acc_t acc[4][4];
+    const int n0 = ct * C::CW;
+    acc_t acc[4][C::NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+      for (int b = 0; b < C::NB; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
     int kb, ke;
     p.krange(m0, n0, bz, kb, ke);
     const int nchunks = (ke > kb) ? ((ke - kb) / C::BK) * R : 0;
     typename P::AVec ra[C::VPT];
-    V rb[C::VPT];
+    V rb[C::VPTB];
     if (nchunks > 0) {
 #pragma unroll
-      for (int i = 0; i < C::VPT; ++i) { ra[i] = p.loadA(actx, i, kb + srow_k, bz); rb[i] = p.loadB(n0, i, kb + srow_k, 0, bz); }
+      for (int i = 0; i < C::VPT; ++i) ra[i] = p.loadA(actx, i, kb + srow_k, bz);
+#pragma unroll
+      for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, kb + srow_k, 0, bz);
     }
     int rep = 0, kA = kb;
     for (int c = 0; c < nchunks; ++c) {
       __syncthreads();
+      if (rep == 0) {
 #pragma unroll
-      for (int i = 0; i < C::VPT; ++i) {
-        const int r = nt_stage_row<T>(i);
-        if (rep == 0) *reinterpret_cast<V*>(&As[r * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
-        *reinterpret_cast<V*>(&Bs[r * C::LDK + srow_k]) = rb[i];
+        for (int i = 0; i < C::VPT; ++i) *reinterpret_cast<V*>(&As[nt_stage_row<T>(i) * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
       }
+#pragma unroll
+      for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
       __syncthreads();
       // prefetch the next chunk's operands into registers while this one is multiplied
       int nrep = rep + 1, nkA = kA;
       if (nrep == R) { nrep = 0; nkA = kA + C::BK; }
       if (c + 1 < nchunks) {
+        if (nrep == 0) {
 #pragma unroll
-        for (int i = 0; i < C::VPT; ++i) {
-          if (nrep == 0) ra[i] = p.loadA(actx, i, nkA + srow_k, bz);
-          rb[i] = p.loadB(n0, i, nkA + srow_k, nrep, bz);
+          for (int i = 0; i < C::VPT; ++i) ra[i] = p.loadA(actx, i, nkA + srow_k, bz);
         }
+#pragma unroll
+        for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, nkA + srow_k, nrep, bz);
       }
       T sc[4];
       if (P::SCALE_A) {
@@ -113,25 +122,26 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
       }
       // fragments: lane (lr, lg) owns k indices lg*KG .. lg*KG+KG-1 of this chunk for row/col lr
       const T* pa = &As[(wr * 64 + lr) * C::LDK + lg * C::KG];
-      const T* pb = &Bs[(wc * 64 + lr) * C::LDK + lg * C::KG];
+      const T* pb = &Bs[(wc * (C::CW / 2) + lr) * C::LDK + lg * C::KG];
 #pragma unroll
       for (int v = 0; v < C::KG / C::VE; ++v) {
-        V fa[4], fb[4];
+        V fa[4], fb[C::NB];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
           fa[t4] = *reinterpret_cast<const V*>(pa + t4 * 16 * C::LDK + v * C::VE);
-          fb[t4] = *reinterpret_cast<const V*>(pb + t4 * 16 * C::LDK + v * C::VE);
           if (P::SCALE_A) {
 #pragma unroll
             for (int e = 0; e < C::VE; ++e) fa[t4][e] *= sc[t4];
           }
         }
 #pragma unroll
+        for (int t4 = 0; t4 < C::NB; ++t4) fb[t4] = *reinterpret_cast<const V*>(pb + t4 * 16 * C::LDK + v * C::VE);
+#pragma unroll
         for (int e = 0; e < C::VE; ++e)
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
+            for (int b = 0; b < C::NB; ++b) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
       }
       rep = nrep; kA = nkA;
     }
@@ -144,7 +154,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void gemm_nt_kernel(
 template <typename T> __device__ __forceinline__ int nt_acc_row(int wr, int a, int lane, int r) {
   return wr * 64 + a * 16 + Mfma<T>::crow(lane, r);
 }
-__device__ __forceinline__ int nt_acc_col(int wc, int b, int lane) { return wc * 64 + b * 16 + (lane & 15); }
+template <typename T> __device__ __forceinline__ int nt_acc_col(int wc, int b, int lane) {
+  return wc * (NTCfg<T>::CW / 2) + b * 16 + (lane & 15);
+}
 
 // default block -> (row tile, column tile) map: column tile fastest
 // default staging: the prefetched A registers already hold the LDS representation

@@ -239,7 +239,7 @@ template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T> {
   T* C; int64_t c_bs;
   int Mp; T alpha;
   struct ACtx { int64_t m0; }; struct ECtx {};
-  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = Mp; }
@@ -254,16 +254,16 @@ template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T> {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(Bt + bz * b_bs + (int64_t)c * Mp + k) : zero();
   }
-  template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int bz, ECtx&, int wr, int wc, int lane) const {
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int bz, ECtx&, int wr, int wc, int lane) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NTCfg<T>::NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
-          const int n = n0 + nt_acc_col(wc, b, lane);
+          const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (m < Mp && n < Mp) C[bz * c_bs + m * Mp + n] = alpha * acc[a][b][r];
         }
   }

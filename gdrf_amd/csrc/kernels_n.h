@@ -124,11 +124,11 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx { T rs[4][4]; int ct; };
-  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const {
-    kb = 0; ke = n0 + GDRF_TILE; if (ke > Mp) ke = Mp;
+    kb = 0; ke = n0 + NTCfg<T>::CW; if (ke > Mp) ke = Mp;
   }
   __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const {
 #pragma unroll
@@ -151,18 +151,18 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(Linv + (int64_t)c * Mp + k) : vzero<T>();
   }
-  template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx& ec, int wr, int wc, int lane) const {
-    ec.ct = n0 / GDRF_TILE;
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx& ec, int wr, int wc, int lane) const {
+    ec.ct = n0 / NTCfg<T>::CW;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NTCfg<T>::NB; ++b) {
           ec.rs[a][r] += acc[a][b][r] * acc[a][b][r];
-          const int n = n0 + nt_acc_col(wc, b, lane);
+          const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (m < nrows && n < Mp) W[m * Mp + n] = (TN)acc[a][b][r];
         }
       }
@@ -203,8 +203,8 @@ template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
   __device__ __forceinline__ V loadB(int, int i, int k, int, int) const {
     return *reinterpret_cast<const V*>(Upad + (int64_t)nt_stage_row<T>(i) * Mp + k);
   }
-  template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int, int, ECtx&, int wr, int wc, int lane) const {
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int, int, ECtx&, int wr, int wc, int lane) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -212,8 +212,8 @@ template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
         const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
         if (m >= nrows) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int k = nt_acc_col(wc, b, lane);
+        for (int b = 0; b < NTCfg<T>::NB; ++b) {
+          const int k = nt_acc_col<T>(wc, b, lane);
           if (k < K) loc[(int64_t)k * ldk + m] = acc[a][b][r];
         }
       }
@@ -230,7 +230,7 @@ template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
   T* tt; int64_t ldt;              // [K][ldt]
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx { T rs[4][4]; };
-  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return true; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const { kb = n0; ke = Mp; }
@@ -254,12 +254,12 @@ template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(ST + ((int64_t)bz * Mp + c) * Mp + k) : vzero<T>();
   }
-  template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t, int, int, ECtx& e, int, int, int) const {
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t, int, int, ECtx& e, int, int, int) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NTCfg<T>::NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) e.rs[a][r] += acc[a][b][r] * acc[a][b][r];
   }
@@ -286,7 +286,7 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
   T* Wbar;
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx {};
-  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return K; }
   __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = Mp; }
@@ -311,8 +311,8 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(Bm + ((int64_t)rep * Mp + c) * Mp + k) : vzero<T>();
   }
-  template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -321,8 +321,8 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
         if (m >= nrows) continue;
         const T as2 = T(2) * asum[m];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int n = n0 + nt_acc_col(wc, b, lane);
+        for (int b = 0; b < NTCfg<T>::NB; ++b) {
+          const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (n >= Mp) continue;
           T v = acc[a][b][r] - as2 * W[m * Mp + n];
           if (n < M) for (int k = 0; k < K; ++k) v += locbar[(int64_t)k * ldk + m] * U[(int64_t)k * M + n];
@@ -344,7 +344,7 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
   double* part;                    // [gridDim.x][2]
   struct ACtx { const TN* p[NTCfg<T>::VPT]; };
   struct ECtx { T s1, s2; };
-  __device__ __forceinline__ int col_tiles() const { return (Mp + GDRF_TILE - 1) / GDRF_TILE; }
+  __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const { kb = n0; ke = Mp; }
@@ -374,13 +374,13 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(LinvT + (int64_t)c * Mp + k) : vzero<T>();
   }
-  template <class Acc>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][4], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
     const T ils2 = (T)h->inv_ls2;
     T z[4][GDRF_DMAX];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int n = n0 + nt_acc_col(wc, b, lane);
+    for (int b = 0; b < NTCfg<T>::NB; ++b) {
+      const int n = n0 + nt_acc_col<T>(wc, b, lane);
 #pragma unroll
       for (int d = 0; d < GDRF_DMAX; ++d) z[b][d] = (n < M && d < D) ? Z[(int64_t)n * D + d] : T(0);
     }
@@ -394,8 +394,8 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
 #pragma unroll
         for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? (T)X[m * D + d] : T(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int n = n0 + nt_acc_col(wc, b, lane);
+        for (int b = 0; b < NTCfg<T>::NB; ++b) {
+          const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (n >= M) continue;
           T r2 = 0;
 #pragma unroll
