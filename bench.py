@@ -196,7 +196,8 @@ def main():
         ms = {k: (v["ms"] / v["count"] if v["count"] else 0.0) for k, v in timing.items()}
         per_step = {k: v["ms"] / args.steps for k, v in timing.items()}
         flops = {  # useful flops per launch (triangular/symmetric halves skipped, nothing counted twice)
-            "fwd_w": 1.0 * n_loc * M * M, "loc": 2.0 * n_loc * M * K, "fwd_t": 1.0 * n_loc * M * M * K, "bwd_wbar": 2.0 * n_loc * M * M * K,
+            "fwd_w": 1.0 * n_loc * M * M, "loc": 2.0 * n_loc * M * K, "fwd_t": 1.0 * n_loc * M * M * K,
+            "bwd_wbar": (1.0 if eng.stores_t else 2.0) * n_loc * M * M * K,   # triangular T_k S_k^T vs dense W B_k
             "bwd_knm": 1.0 * n_loc * M * M, "tn_sym": 1.0 * n_loc * M * M * K, "tn_gt": 2.0 * n_loc * M * M,
         }
         dom = max(flops, key=lambda k: per_step[k])
@@ -216,7 +217,7 @@ def main():
                                    f"M={M} ({'x'.join(map(str, args.n_points))} grid inducing points), {args.kernel} kernel, "
                                    f"Adam lr=1e-3, Trace_ELBO, 1 particle, jitter={args.jitter}, observations sharded over ranks",
                        "N": N, "M": M, "K": K, "V": args.vocab, "D": D, "rows_per_rank": n_loc,
-                       "jitter_level": eng.last_jitter_level},
+                       "jitter_level": eng.last_jitter_level, "stores_T": eng.stores_t},
             "roofline": {"bound": "mfma", "kernel": f"gemm_nt<{dom}>" if not dom.startswith("tn") else f"gemm_tn<{dom}>",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "flops_per_launch": flops[dom], "avg_ms": ms[dom]},

@@ -17,6 +17,8 @@ SIGNATURES = {
     "gdrf_last_error": (C.c_char_p, []),
     "gdrf_version": (_int, []),
     "gdrf_ctx_create": (_int, [C.POINTER(_vp), _int, _i64, _int, _int, _int, _int, _int, _int]),
+    "gdrf_ctx_create_ex": (_int, [C.POINTER(_vp), _int, _i64, _int, _int, _int, _int, _int, _int, _int]),
+    "gdrf_stores_t": (_int, [_vp]),
     "gdrf_ctx_destroy": (None, [_vp]),
     "gdrf_param_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_red_layout": (_int, [_vp, C.POINTER(_i64)]),
@@ -24,7 +26,7 @@ SIGNATURES = {
     "gdrf_knm": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gdrf_fill_eps": (_int, [_vp, C.c_uint64, C.c_uint32, _i64, _i64, _vp, _vp]),
     "gdrf_ll_const": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), _vp]),
-    "gdrf_probe": (_int, [_vp, _vp, _vp, _dbl, _vp]),
+    "gdrf_probe": (_int, [_vp, _vp, _vp, C.POINTER(_dbl), _int, C.POINTER(_int), _vp]),
     "gdrf_factorize": (_int, [_vp, _vp, _vp, _dbl, _vp]),
     "gdrf_step_local": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gdrf_step_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),

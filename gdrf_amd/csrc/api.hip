@@ -49,10 +49,11 @@ struct gdrf_ctx {
   void *Knm;                  // [ncap][Mp] K_nm in the solve precision (forward A operand, backward epilogue)
   // probe (N-side precision) scratch, only when T != TS
   void *pK, *pL;
-  double probe_jitter; int probe_ok;
   // N-side precision
   void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
+  void *Tst;                  // T_k = W S_k kept for the backward, or nullptr (dense W B_k form instead)
+  int64_t t_bs, t_ts;         // its per-topic / per-row-tile strides in elements
   void *slab, *ubar_part, *phibar_part;
   double *dpart, *dsmall;     // dsmall: [0..1] kuu sums, [8] ll_const scratch
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
@@ -124,6 +125,10 @@ static int tn_nsplit(const gdrf_ctx* c, int64_t n, int BR) {
 }
 
 int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id) {
+  return gdrf_ctx_create_ex(out, device, n_cap, M, K, V, D, dtype, kernel_id, GDRF_STORE_T_OFF);
+}
+
+int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id, int store_t) {
   if (!out || n_cap < 1 || M < 1 || K < 1 || V < 1 || D < 1) return fail(-1, "gdrf_ctx_create", "bad size");
   if (K > GDRF_KMAX) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 32 not supported");
   if (D > GDRF_DMAX) return fail(-1, "gdrf_ctx_create", "more than 4 input dimensions not supported");
@@ -136,8 +141,8 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   c->esz = dtype == GDRF_F64 ? 8 : 4;
   c->ssz = dtype == GDRF_F32_PURE ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
-  c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0; c->probe_ok = 0; c->probe_jitter = -1;
-  c->pK = c->pL = nullptr;
+  c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
+  c->pK = c->pL = nullptr; c->Tst = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -153,7 +158,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
   AL(c->Cf, (size_t)K * M * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
   AL(c->Knm, (size_t)n_cap * c->Mp * c->ssz)
-  if (c->esz != c->ssz) { AL(c->pK, mm) AL(c->pL, mm) }
+  AL(c->pK, mm) AL(c->pL, mm * 8)          // probe scratch: K_uu without jitter, 8 level copies
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
   AL(c->phi, (size_t)K * V * c->esz)
   AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)((c->Mp + 63) / 64) * c->ldk * c->esz)
@@ -161,6 +166,18 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   AL(c->q, (size_t)c->ldk * c->esz) AL(c->asum, (size_t)c->ldk * c->esz)
   AL(c->loc, (size_t)K * c->ldk * c->esz) AL(c->tt, (size_t)K * c->ldk * c->esz) AL(c->vbar, (size_t)K * c->ldk * c->esz)
   AL(c->locbar, (size_t)K * c->ldk * c->esz) AL(c->mu, (size_t)K * c->ldk * c->esz)
+  {
+    // GDRF_STORE_T_AUTO would keep T_k when it fits comfortably (<= 64 GB and <= 40 % of the free HBM); measured on
+    // MI355X the stored-T form is currently SLOWER (47 vs 43 ms at the headline size: its A operand is a cold HBM
+    // stream on every chunk and the register prefetch is drained by vmcnt(0) waits), so AUTO resolves to OFF.
+    c->t_ts = (int64_t)GDRF_TILE * c->Mp + 1536;                                   // + 6 KB (f32): not a power of two
+    c->t_bs = c->t_ts * ((n_cap + GDRF_TILE - 1) / GDRF_TILE) + 40960 + 512;
+    const size_t tbytes = (size_t)K * c->t_bs * c->esz;
+    size_t fr = 0, tot = 0;
+    (void)hipMemGetInfo(&fr, &tot);
+    const bool want = store_t == GDRF_STORE_T_ON && tbytes <= ((size_t)64 << 30) && tbytes * 5 <= fr * 2 + tbytes * 5 * (fr == 0);
+    if (want) { AL(c->Tst, tbytes) }
+  }
   c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
   AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
   c->ubar_blocks_cap = (n_cap + 2047) / 2048;
@@ -172,9 +189,9 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
-  AL(c->hyp, sizeof(Hyper)) AL(c->flag, 16)
+  AL(c->hyp, sizeof(Hyper)) AL(c->flag, 64)
 #undef AL
-  HIPCHK(hipMemset(c->flag, 0, 16));
+  HIPCHK(hipMemset(c->flag, 0, 64));
   HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
   std::vector<double> a((size_t)K * V, 1.0);
   *out = c;
@@ -227,6 +244,7 @@ static int ws_lookup(gdrf_ctx* c, int which, void** ptr, int64_t* nelem, int* es
   return 0;
 }
 int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) { int e; return ws_lookup(c, which, ptr, nelem, &e); }
+int gdrf_stores_t(const gdrf_ctx* c) { return c->Tst != nullptr; }
 int gdrf_ws_elem_size(gdrf_ctx* c, int which) { void* p; int64_t n; int e; return ws_lookup(c, which, &p, &n, &e) ? -1 : e; }
 
 int gdrf_set_timing(gdrf_ctx* c, int enable) {
@@ -281,20 +299,23 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
-  // one Cholesky attempt in the N-side precision (what the reference's fp32 torch.linalg.cholesky would see)
-  static int probe(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
+  // nlev (<= 8) Cholesky attempts in ONE launch, in the N-side precision (what the reference's fp32
+  // torch.linalg.cholesky would see): K_uu built once, one workgroup per cumulative jitter; flags in c->flag[0..nlev)
+  static int probe(gdrf_ctx* c, const T* Z, const T* params, const double* jitters, int nlev, hipStream_t s) {
     const int Mp = c->Mp, M = c->M;
     ScopedTimer tm(c, 0, s);
-    HIPCHK(hipMemsetAsync(c->flag, 0, 16, s));
+    HIPCHK(hipMemsetAsync(c->flag, 0, 64, s));
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     dim3 g2((Mp + 255) / 256, Mp);
-    T* K_ = kSame ? P(c->Kuu) : P(c->pK);
-    T* L_ = kSame ? P(c->Lw) : P(c->pL);
-    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp, jitter, K_);
-    HIPCHK(hipMemcpyAsync(L_, K_, (size_t)Mp * Mp * sizeof(T), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(chol_kernel<T>, dim3(1), dim3(1024), 0, s, L_, M, Mp, c->flag);
+    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp, 0.0, P(c->pK));
+    JitterLevels jl;
+    for (int l = 0; l < 8; ++l) jl.v[l] = l < nlev ? jitters[l] : 0.0;
+    dim3 g3((Mp + 255) / 256, Mp, nlev);
+    hipLaunchKernelGGL(level_copies_kernel<T>, g3, dim3(256), 0, s, (const T*)P(c->pK), M, Mp, jl, P(c->pL));
+    if (chol_lds_bytes<T>(M) > 48 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<T>(M)));
+    hipLaunchKernelGGL(chol_kernel<T>, dim3(nlev), dim3(1024), chol_lds_bytes<T>(M), s, P(c->pL), M, Mp, c->flag, (int64_t)Mp * Mp);
     LAUNCHCHK("probe");
-    c->probe_jitter = jitter; c->probe_ok = 1;
     return 0;
   }
 
@@ -306,14 +327,12 @@ template <typename T, typename TS> struct Impl {
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     const int64_t nz = (int64_t)M * c->D;
     hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, nz, Z, Q(c->Zs));
-    const bool reuse = kSame && c->probe_ok && c->probe_jitter == jitter;      // the probe already factorised this matrix
-    if (!reuse) {
-      HIPCHK(hipMemsetAsync(c->flag, 0, 16, s));
-      hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
-      HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), 0, s, Q(c->Lw), M, Mp, c->flag);
-    }
-    c->probe_ok = 0;
+    HIPCHK(hipMemsetAsync(c->flag, 0, 64, s));
+    hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
+    HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, s));
+    if (chol_lds_bytes<TS>(M) > 48 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<TS>(M)));
+    hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), s, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
     hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
     hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, s, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
     hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(1024), 0, s, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
@@ -363,7 +382,7 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
       hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
       hipLaunchKernelGGL(build_upad_kernel<T>, dim3((Mp + 255) / 256, GDRF_TILE), dim3(256), 0, s, U, K, M, Mp, P(c->Upad));
-      if ((rc = mm_nt<T>(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
+      if (!c->Tst && (rc = mm_nt<T>(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
     }
     const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
     // (1) W = Knm Linv^T in the solve precision, stored in the N-side precision
@@ -382,7 +401,7 @@ template <typename T, typename TS> struct Impl {
     // (2) tt_kn = ||S_k^T w_n||^2
     {
       ScopedTimer tm(c, 5, s);
-      FwdTProb<T> p{{}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk};
+      FwdTProb<T> p{{}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
     }
     LAUNCHCHK("forward");
@@ -408,11 +427,20 @@ template <typename T, typename TS> struct Impl {
     // (3) Wbar
     {
       ScopedTimer tm(c, 7, s);
-      BwdWbarProb<T> p{{}, {}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
       const size_t lds = C::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(T);
-      if (lds > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), dim3((unsigned)round_up(rtiles * nct<T>(c), 8)), dim3(256), lds, s, p);
+      const dim3 grid(c->Tst ? nt_xcd_pair_grid(rtiles, nct<T>(c)) : (unsigned)round_up(rtiles * nct<T>(c), 8));
+      if (c->Tst) {
+        BwdWbarTProb<T> p{{}, {}, P(c->Tst), c->t_bs, c->t_ts, P(c->W), n, M, Mp, K, P(c->S), P(c->vbar), P(c->locbar), ldk,
+                          P(c->asum), U, P(c->Wbar)};
+        if (lds > 48 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarTProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarTProb<T>>), grid, dim3(256), lds, s, p);
+      } else {
+        BwdWbarProb<T> p{{}, {}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
+        if (lds > 48 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), grid, dim3(256), lds, s, p);
+      }
     }
     // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
@@ -549,10 +577,20 @@ int gdrf_ll_const(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_host, v
     { using T = float; using I = Impl<float, float>; return I::fn(__VA_ARGS__); }                                  \
   } while (0)
 
-int gdrf_probe(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream) {
+static int probe_dispatch(gdrf_ctx* c, const void* Z, const void* params, const double* jitters, int nlev, hipStream_t s) {
+  TYPED3(c, probe, c, (const T*)Z, (const T*)params, jitters, nlev, s);
+}
+
+int gdrf_probe(gdrf_ctx* c, const void* Z, const void* params, const double* jitters, int nlev, int* failed_host, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
+  if (nlev < 1 || nlev > 8) return fail(-1, "gdrf_probe", "nlev must be in [1, 8]");
   hipStream_t s = (hipStream_t)stream;
-  TYPED3(c, probe, c, (const T*)Z, (const T*)params, jitter, s);
+  int rc = probe_dispatch(c, Z, params, jitters, nlev, s);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(failed_host, c->flag, sizeof(int) * nlev, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemsetAsync(c->flag, 0, 64, s));
+  return 0;
 }
 
 int gdrf_factorize(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream) {

@@ -11,6 +11,8 @@
 //
 // The problem object P supplies operands and epilogue:
 //   static constexpr bool SCALE_A         per-(repeat,row) scale of the A fragments from LDS
+//   static constexpr bool A_PER_REP       the A chunk itself depends on the repeat (topic): staged for every chunk
+//   static constexpr int  DEPTH           register prefetch distance in chunks (1, or 2 for cold HBM streams)
 //   int  col_tiles(); bool loop_cols();   loop_cols: one workgroup walks every column tile of its row tile
 //   int  a_reuse()
 //   int  extra_lds_bytes()                problem-owned LDS behind the two staging tiles
@@ -86,35 +88,39 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
     int kb, ke;
     p.krange(m0, n0, bz, kb, ke);
     const int nchunks = (ke > kb) ? ((ke - kb) / C::BK) * R : 0;
-    typename P::AVec ra[C::VPT];
-    V rb[C::VPTB];
-    if (nchunks > 0) {
+    // chunk c -> (A column kA, repeat rep).  With a shared A chunk the repeats are innermost (A staged once per R
+    // chunks); when A itself depends on the repeat, k is innermost so each repeat's A stream is contiguous in HBM.
+    const int nk = (ke > kb) ? (ke - kb) / C::BK : 0;
+    auto chunk_pos = [&](int c, int& kA, int& rep) {
+      if (P::A_PER_REP) { rep = c / nk; kA = kb + (c - rep * nk) * C::BK; }
+      else { const int q = c / R; rep = c - q * R; kA = kb + q * C::BK; }
+    };
+    // register prefetch: DEPTH chunks ahead of the one being multiplied (DEPTH = 2 for operands that come cold
+    // from HBM on every chunk; the sets are named so that every register index stays static)
+    typename P::AVec ra0[C::VPT], ra1[C::VPT];
+    V rb0[C::VPTB], rb1[C::VPTB];
+    auto gload = [&](typename P::AVec (&ra)[C::VPT], V (&rb)[C::VPTB], int c) {
+      int kA, rep;
+      chunk_pos(c, kA, rep);
+      if (rep == 0 || P::A_PER_REP) {
 #pragma unroll
-      for (int i = 0; i < C::VPT; ++i) ra[i] = p.loadA(actx, i, kb + srow_k, bz);
+        for (int i = 0; i < C::VPT; ++i) ra[i] = p.loadA(actx, i, kA + srow_k, rep, bz);
+      }
 #pragma unroll
-      for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, kb + srow_k, 0, bz);
-    }
-    int rep = 0, kA = kb;
-    for (int c = 0; c < nchunks; ++c) {
+      for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, kA + srow_k, rep, bz);
+    };
+    auto body = [&](typename P::AVec (&ra)[C::VPT], V (&rb)[C::VPTB], int c) {
+      int kA, rep;
+      chunk_pos(c, kA, rep);
       __syncthreads();
-      if (rep == 0) {
+      if (rep == 0 || P::A_PER_REP) {
 #pragma unroll
         for (int i = 0; i < C::VPT; ++i) *reinterpret_cast<V*>(&As[nt_stage_row<T>(i) * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
       }
 #pragma unroll
       for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
       __syncthreads();
-      // prefetch the next chunk's operands into registers while this one is multiplied
-      int nrep = rep + 1, nkA = kA;
-      if (nrep == R) { nrep = 0; nkA = kA + C::BK; }
-      if (c + 1 < nchunks) {
-        if (nrep == 0) {
-#pragma unroll
-          for (int i = 0; i < C::VPT; ++i) ra[i] = p.loadA(actx, i, nkA + srow_k, bz);
-        }
-#pragma unroll
-        for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, nkA + srow_k, nrep, bz);
-      }
+      if (c + P::DEPTH < nchunks) gload(ra, rb, c + P::DEPTH);      // refill the set just consumed
       T sc[4];
       if (P::SCALE_A) {
 #pragma unroll
@@ -143,7 +149,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
 #pragma unroll
             for (int b = 0; b < C::NB; ++b) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
       }
-      rep = nrep; kA = nkA;
+    };
+    if (P::DEPTH == 1) {
+      if (nchunks > 0) gload(ra0, rb0, 0);
+      for (int c = 0; c < nchunks; ++c) body(ra0, rb0, c);
+    } else {
+      if (nchunks > 0) gload(ra0, rb0, 0);
+      if (nchunks > 1) gload(ra1, rb1, 1);
+      for (int c = 0; c < nchunks; c += 2) {
+        body(ra0, rb0, c);
+        if (c + 1 < nchunks) body(ra1, rb1, c + 1);
+      }
     }
     p.tile_done(acc, m0, n0, bz, ectx, wr, wc, lane);
   }
@@ -180,6 +196,29 @@ struct NTXcdMap {
     const unsigned xcd = bid & 7u, idx = bid >> 3, per = 8u / (unsigned)nct;   // XCDs per column tile
     ct = (int)(xcd % (unsigned)nct);
     rtile = (int64_t)idx * per + xcd / (unsigned)nct;
+  }
+};
+
+// XCD-aware map for TRIANGULAR reductions, where column tile ct costs (ct+1) units: column tiles are paired
+// (ct, nct-1-ct) so that every XCD alternates a light and a heavy tile (equal work per XCD) while still keeping
+// only two tiles' B panels in its L2.  The XCDs that share a pair deal the row tiles round-robin.
+// Grid: nt_xcd_pair_grid(rtiles, nct).  Falls back to the default order when nct is odd or does not divide 8.
+__host__ __device__ inline bool nt_xcd_pair_ok(int nct) { return nct >= 2 && nct <= 8 && (nct % 2) == 0 && (8 % nct) == 0; }
+inline unsigned nt_xcd_pair_grid(int64_t rtiles, int nct) {
+  if (!nt_xcd_pair_ok(nct)) return (unsigned)(rtiles * nct);
+  const int nper = 8 / (nct / 2);
+  return (unsigned)(16 * ((rtiles + nper - 1) / nper));
+}
+struct NTXcdPairMap {
+  __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
+    if (loopc) { rtile = bid; ct = 0; return; }
+    if (!nt_xcd_pair_ok(nct)) { rtile = bid / nct; ct = (int)(bid % nct); return; }
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const int c = (int)(xcd % (unsigned)nct), half = nct / 2, nper = 8 / half;
+    const int pid = c < half ? c : nct - 1 - c;
+    const int r = (int)(xcd / (unsigned)nct) * 2 + (c >= half ? 1 : 0);
+    rtile = (int64_t)(idx >> 1) * nper + r;
+    ct = (idx & 1u) ? nct - 1 - pid : pid;
   }
 };
 

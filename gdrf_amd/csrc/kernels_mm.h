@@ -46,50 +46,121 @@ __global__ void kuu_kernel(const T* __restrict__ Z, int M, int Mp, int D, int ki
 }
 
 // ---- single-workgroup blocked left-looking Cholesky (panel 32), in place on the lower triangle.
-// A pivot <= 0 (or NaN) sets *flag and is replaced by 1 so that everything downstream stays finite;
-// the optimizer update is predicated on the flag and the host retries with the reference's
-// cumulative jitter schedule.
+// Per panel c0:
+//   (a) U = A[c0:M, c0:c0+32] - L[c0:M, 0:c0] L[c0:c0+32, 0:c0]^T on the matrix cores: the 32 panel rows of L are
+//       staged in LDS (B operand), every wave owns 16-row strips of U and streams its A operand (16 rows x 16
+//       reduction indices per 16-byte load) straight from L2; 2 MFMA column tiles per strip.
+//   (b) the 32x32 diagonal block of U is factored by ONE wave, one row per lane, rows in registers, the current
+//       column broadcast through LDS (no workgroup barriers inside the column loop);
+//   (c) rows below: X = U Ld^{-T} with Ld^{-1} from forward substitution (one column per lane).
+// A pivot <= 0 (or NaN) sets *flag and is replaced by 1 so that everything downstream stays finite; the optimizer
+// update is predicated on the flag and the host retries with the reference's cumulative jitter schedule.
+// blockIdx.x selects an independent problem: matrix A + blockIdx.x * batch_stride, flag[blockIdx.x] (the jitter
+// probe factorises the same K_uu with several cumulative jitters in one launch).
+#define CHOL_PC 256
 template <typename T>
-__global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, int ld, int* __restrict__ flag) {
-  __shared__ T Sa[32][33];
-  __shared__ T Sb[32][33];
+__global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, int ld, int* __restrict__ flag, int64_t batch_stride) {
+  using MM = Mfma<T>;
+  using acc_t = typename MM::acc_t;
+  using V = typename Vec16<T>::type;
+  constexpr int VE = Vec16<T>::N;            // elements per 16-byte vector: 4 (f32) / 2 (f64)
+  constexpr int KC = 4 * VE;                 // reduction indices per staged step: lane group g owns VE of them
+  extern __shared__ __attribute__((aligned(16))) char smem_chol[];
+  T* Lp = reinterpret_cast<T*>(smem_chol);   // [32][ldp] one column chunk of the panel rows L[c0:c0+32, pc:pc+CHOL_PC]
+  constexpr int ldp = CHOL_PC + VE;          // row stride of Lp (elements), 16-byte aligned, bank-shifted
+  T (*Sa)[33] = reinterpret_cast<T (*)[33]>(Lp + 32 * ldp);
+  T (*Sb)[33] = Sa + 32;
+  T* Scol = reinterpret_cast<T*>(Sb + 32);   // [32]
+  A += (int64_t)blockIdx.x * batch_stride;
+  flag += blockIdx.x;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   for (int c0 = 0; c0 < M; c0 += 32) {
-    // (a) panel update: A[i][c0+tx] -= sum_{p<c0} A[i][p] * A[c0+tx][p] for every row block i0 >= c0
-    for (int i0 = c0; i0 < M; i0 += 32) {
-      T acc = 0;
-      for (int p0 = 0; p0 < c0; p0 += 32) {
-        Sa[ty][tx] = (i0 + ty < M) ? A[(int64_t)(i0 + ty) * ld + p0 + tx] : T(0);
-        Sb[ty][tx] = (c0 + ty < M) ? A[(int64_t)(c0 + ty) * ld + p0 + tx] : T(0);
-        __syncthreads();
+    // ---- (a) panel update.  The panel rows are staged in column chunks of CHOL_PC; a wave keeps the accumulators
+    //      of up to NS of its strips across the chunks (more strips: another pass over the chunks).
+    if (c0 > 0) {
+      const int nstrips = (M - c0 + 15) / 16;
+      constexpr int NS = sizeof(T) == 4 ? 4 : 2;             // strips whose accumulators a wave carries at once
+      for (int sg = 0; sg * 16 * NS < nstrips; ++sg) {     // strips sg*16*NS + wave + 16*s, s = 0..NS-1
+        acc_t acc[NS][2];
 #pragma unroll
-        for (int p = 0; p < 32; ++p) acc += Sa[ty][p] * Sb[tx][p];
-        __syncthreads();
+        for (int s4 = 0; s4 < NS; ++s4) { acc[s4][0] = acc_t{0, 0, 0, 0}; acc[s4][1] = acc_t{0, 0, 0, 0}; }
+        for (int pc = 0; pc < c0; pc += CHOL_PC) {
+          const int pw = (c0 - pc < CHOL_PC) ? (c0 - pc) : CHOL_PC;      // multiple of 32
+          __syncthreads();
+          for (int e = tid; e < 32 * pw; e += 1024) {
+            const int r = e / pw, q = e - r * pw;
+            Lp[r * ldp + q] = (c0 + r < M) ? A[(int64_t)(c0 + r) * ld + pc + q] : T(0);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int s4 = 0; s4 < NS; ++s4) {
+            const int st = sg * 16 * NS + wave + 16 * s4;
+            if (st >= nstrips) continue;
+            const int row = c0 + st * 16 + lr;
+            const bool rok = row < M;
+            const T* arow = A + (int64_t)(rok ? row : 0) * ld + pc;
+            for (int p0 = 0; p0 < pw; p0 += KC) {
+              V a = *reinterpret_cast<const V*>(arow + p0 + lg * VE);
+              if (!rok) { for (int e = 0; e < VE; ++e) a[e] = 0; }
+              const V b0 = *reinterpret_cast<const V*>(Lp + lr * ldp + p0 + lg * VE);
+              const V b1 = *reinterpret_cast<const V*>(Lp + (16 + lr) * ldp + p0 + lg * VE);
+#pragma unroll
+              for (int e = 0; e < VE; ++e) { acc[s4][0] = MM::mma(a[e], b0[e], acc[s4][0]); acc[s4][1] = MM::mma(a[e], b1[e], acc[s4][1]); }
+            }
+          }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < NS; ++s4) {
+          const int st = sg * 16 * NS + wave + 16 * s4;
+          if (st >= nstrips) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = c0 + st * 16 + MM::crow(lane, r);
+            if (i < M) {
+              if (c0 + lr < M) A[(int64_t)i * ld + c0 + lr] -= acc[s4][0][r];
+              if (c0 + 16 + lr < M) A[(int64_t)i * ld + c0 + 16 + lr] -= acc[s4][1][r];
+            }
+          }
+        }
       }
-      if (c0 > 0 && i0 + ty < M && c0 + tx < M) A[(int64_t)(i0 + ty) * ld + c0 + tx] -= acc;
+      __syncthreads();
+    }
+    // ---- (b) factor the 32x32 diagonal block: one wave, one row per lane
+    if (wave == 0) {
+      const int l = lane & 31;                 // lanes 32..63 mirror lanes 0..31 (same values, same writes)
+      T x[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const bool in = (c0 + l < M) && (c0 + j < M);
+        x[j] = in ? A[(int64_t)(c0 + l) * ld + c0 + j] : ((l == j) ? T(1) : T(0));
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        T d = __shfl(x[j], j, 64);
+        if (!(d > T(0))) { if (lane == 0 && c0 + j < M) *flag = 1; d = T(1); }
+        const T piv = t_sqrt<T>(d);
+        x[j] = (l == j) ? piv : ((l > j) ? x[j] / piv : T(0));
+        Scol[l] = x[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = j + 1; c < 32; ++c) {
+          const T lcj = Scol[c];
+          if (l >= c) x[c] -= x[j] * lcj;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          Sa[l][j] = x[j];
+          if (c0 + l < M && c0 + j < M) A[(int64_t)(c0 + l) * ld + c0 + j] = x[j];
+        }
+      }
     }
     __syncthreads();
-    // (b) factor the 32x32 diagonal block in LDS
-    {
-      const bool in = (c0 + ty < M) && (c0 + tx < M);
-      Sa[ty][tx] = in ? A[(int64_t)(c0 + ty) * ld + c0 + tx] : ((ty == tx) ? T(1) : T(0));
-    }
-    __syncthreads();
-    for (int j = 0; j < 32; ++j) {
-      if (tid == 0) {
-        T d = Sa[j][j];
-        if (!(d > T(0))) { if (c0 + j < M) *flag = 1; d = T(1); }
-        Sa[j][j] = t_sqrt<T>(d);
-      }
-      __syncthreads();
-      if (ty == 0 && tx > j) Sa[tx][j] /= Sa[j][j];
-      __syncthreads();
-      if (tx > j && ty >= tx) Sa[ty][tx] -= Sa[ty][j] * Sa[tx][j];
-      __syncthreads();
-    }
-    if (c0 + ty < M && c0 + tx < M) A[(int64_t)(c0 + ty) * ld + c0 + tx] = (tx <= ty) ? Sa[ty][tx] : T(0);
-    // (c) rows below the block: X = A_panel * Ld^{-T}.  Ld^{-1} by forward substitution (one column per
-    // thread) into Sb, then a 32-deep product per element.
+    // ---- (c) rows below the block: X = U Ld^{-T}.  Ld^{-1} by forward substitution (one column per thread) into Sb
     Sb[ty][tx] = 0;
     __syncthreads();
     if (tid < 32) {
@@ -97,7 +168,7 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
       Sb[c][c] = T(1) / Sa[c][c];
       for (int r = c + 1; r < 32; ++r) {
         T s = 0;
-        for (int p = c; p < r; ++p) s += Sa[r][p] * Sb[p][c];
+        for (int q = c; q < r; ++q) s += Sa[r][q] * Sb[q][c];
         Sb[r][c] = -s / Sa[r][r];
       }
     }
@@ -109,11 +180,28 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
       __syncthreads();
       T o = 0;
 #pragma unroll
-      for (int p = 0; p < 32; ++p) o += Sa[ty][p] * Sb[tx][p];     // x_j = sum_p a_p Linv[j][p]
+      for (int q = 0; q < 32; ++q) o += Sa[ty][q] * Sb[tx][q];     // x_j = sum_q a_q Linv[j][q]
       if (i0 + ty < M) A[(int64_t)(i0 + ty) * ld + c0 + tx] = o;
     }
     __syncthreads();
   }
+}
+
+// dynamic LDS bytes of chol_kernel<T>
+template <typename T> inline size_t chol_lds_bytes(int) {
+  const size_t ldp = CHOL_PC + Vec16<T>::N;
+  return (32 * ldp + 2 * 32 * 33 + 32) * sizeof(T);
+}
+
+// nlev copies of K (no jitter) with jitters[lev] added to the diagonal of copy lev
+struct JitterLevels { double v[8]; };
+template <typename T>
+__global__ void level_copies_kernel(const T* __restrict__ K0, int M, int Mp, JitterLevels jl, T* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, lev = blockIdx.z;
+  if (j >= Mp) return;
+  T v = K0[(int64_t)i * Mp + j];
+  if (i == j && i < M) v += (T)jl.v[lev];
+  out[((int64_t)lev * Mp + i) * Mp + j] = v;
 }
 
 // L (strict upper and padding zeroed) and its transpose
@@ -234,6 +322,8 @@ __global__ void build_phi_kernel(const T* __restrict__ phi_unc, int K, int V, T*
 template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
+  static constexpr bool A_PER_REP = false;
+  static constexpr int DEPTH = 1;
   const T* A; int64_t a_bs;
   const T* Bt; int64_t b_bs;
   T* C; int64_t c_bs;
@@ -246,7 +336,7 @@ template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T> {
   __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const { c.m0 = m0; }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
   __device__ __forceinline__ V zero() const { V z; for (int e = 0; e < Vec16<T>::N; ++e) z[e] = 0; return z; }
-  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int bz) const {
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int, int bz) const {
     const int64_t r = c.m0 + nt_stage_row<T>(i);
     return (r < Mp) ? *reinterpret_cast<const V*>(A + bz * a_bs + r * Mp + k) : zero();
   }

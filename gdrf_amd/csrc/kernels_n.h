@@ -120,6 +120,8 @@ template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2,
 template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
+  static constexpr bool A_PER_REP = false;
+  static constexpr int DEPTH = 1;
   const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
@@ -144,7 +146,7 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
       for (int r = 0; r < 4; ++r) e.rs[a][r] = 0;
     e.ct = 0;
   }
-  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int, int) const {
     return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int, int) const {
@@ -181,6 +183,8 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
 template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
+  static constexpr bool A_PER_REP = false;
+  static constexpr int DEPTH = 1;
   const T* W; int64_t nrows; int Mp, K;
   const T* Upad; T* loc; int64_t ldk;
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
@@ -197,7 +201,7 @@ template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
     }
   }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
-  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int, int) const {
     return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
   __device__ __forceinline__ V loadB(int, int i, int k, int, int) const {
@@ -225,9 +229,14 @@ template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
 template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
+  static constexpr bool A_PER_REP = false;
+  static constexpr int DEPTH = 1;
   const T* W; int64_t nrows; int Mp;
   const T* ST;                     // [K][Mp][Mp], ST[k][j][i] = S_k[i][j]
   T* tt; int64_t ldt;              // [K][ldt]
+  T* Tst; int64_t t_bs, t_ts;      // optional T_k kept for the backward (nullptr: not stored), chunk-major blocks:
+                                   // [K][row tile][k chunk][128 rows][BK]; t_bs / t_ts = elements per topic / row tile
+                                   // (both padded away from powers of two: HBM channel interleave)
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx { T rs[4][4]; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
@@ -247,7 +256,7 @@ template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
 #pragma unroll
       for (int r = 0; r < 4; ++r) e.rs[a][r] = 0;
   }
-  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int, int) const {
     return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int, int bz) const {
@@ -255,13 +264,28 @@ template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
     return (c < Mp) ? *reinterpret_cast<const V*>(ST + ((int64_t)bz * Mp + c) * Mp + k) : vzero<T>();
   }
   template <class Acc, int NB_>
-  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t, int, int, ECtx& e, int, int, int) const {
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int bz, ECtx& e, int wr, int wc, int lane) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < NTCfg<T>::NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) e.rs[a][r] += acc[a][b][r] * acc[a][b][r];
+    if (Tst) {
+      constexpr int BK = NTCfg<T>::BK;
+      T* base = Tst + (int64_t)bz * t_bs + (m0 / GDRF_TILE) * t_ts;     // this row tile's blocks
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = nt_acc_row<T>(wr, a, lane, r);
+#pragma unroll
+          for (int b = 0; b < NTCfg<T>::NB; ++b) {
+            const int n = n0 + nt_acc_col<T>(wc, b, lane);
+            if (n < Mp) base[((int64_t)(n / BK) * GDRF_TILE + row) * BK + (n % BK)] = acc[a][b][r];
+          }
+        }
+    }
   }
   __device__ __forceinline__ void finish(int64_t m0, int bz, ECtx& e, char* smem, int wr, int wc, int lane) const {
     T* rsum = reinterpret_cast<T*>(smem);      // [128]
@@ -278,6 +302,8 @@ template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
 template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = true;
+  static constexpr bool A_PER_REP = false;
+  static constexpr int DEPTH = 1;
   const T* W; int64_t nrows; int M, Mp, K;
   const T* Bm;                     // [K][Mp][Mp] symmetric B_k = S_k S_k^T
   const T* vbar; const T* locbar; int64_t ldk;   // [K][ldk]
@@ -304,7 +330,7 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
     }
   }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
-  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int) const {
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int, int) const {
     return c.p[i] ? *reinterpret_cast<const V*>(c.p[i] + k) : vzero<T>();
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int rep, int) const {
@@ -333,10 +359,76 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
   __device__ __forceinline__ void finish(int64_t, int, ECtx&, char*, int, int, int) const {}
 };
 
+// (3') the same Wbar from the stored T_k:  Wbar = sum_k diag(2 vbar_k) T_k S_k^T + locbar^T U - 2 diag(asum) W.
+//      Triangular (j <= i): half the flops of (3).  A = T_k (changes with the topic: A_PER_REP), Bt = S_k row-major.
+template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
+  using V = typename Vec16<T>::type;
+  static constexpr bool SCALE_A = true;
+  static constexpr bool A_PER_REP = true;
+  static constexpr int DEPTH = 1;   // 2 compiles, but hipcc drains it with vmcnt(0) at every wait: no gain
+  const T* Tst; int64_t t_bs, t_ts; const T* W; int64_t nrows; int M, Mp, K;
+  const T* S;                      // [K][Mp][Mp] lower triangular
+  const T* vbar; const T* locbar; int64_t ldk;
+  const T* asum; const T* U; T* Wbar;
+  struct ACtx { int64_t tile_off; bool ok; };
+  struct ECtx {};
+  __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
+  __device__ __forceinline__ bool loop_cols() const { return false; }
+  __device__ __forceinline__ int a_reuse() const { return K; }
+  __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const {
+    kb = 0; ke = n0 + NTCfg<T>::CW; if (ke > Mp) ke = Mp;
+  }
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char* extra) const {
+    T* sc = reinterpret_cast<T*>(extra);          // [K][128]
+    for (int e = threadIdx.x; e < K * GDRF_TILE; e += 256) {
+      const int k = e / GDRF_TILE, r = e - k * GDRF_TILE;
+      sc[e] = (m0 + r < nrows) ? T(2) * vbar[(int64_t)k * ldk + m0 + r] : T(0);
+    }
+    __syncthreads();
+    c.tile_off = (m0 / GDRF_TILE) * t_ts;
+    c.ok = m0 < nrows;       // the launch grid is rounded up to a multiple of 8: padding workgroups own no tile
+  }
+  __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
+  // chunk-major blocks [k chunk][128 rows][BK]: one staged chunk is 16 KB of contiguous memory (rows beyond nrows
+  // of the last tile were written by the forward as zeros-times-S = 0)
+  __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int rep, int) const {
+    constexpr int BK = NTCfg<T>::BK;
+    if (!c.ok) return vzero<T>();
+    return *reinterpret_cast<const V*>(Tst + (int64_t)rep * t_bs + c.tile_off +
+                                       ((int64_t)(k / BK) * GDRF_TILE + nt_stage_row<T>(i)) * BK + (k % BK));
+  }
+  __device__ __forceinline__ V loadB(int n0, int i, int k, int rep, int) const {
+    const int c = n0 + nt_stage_row<T>(i);
+    return (c < Mp) ? *reinterpret_cast<const V*>(S + ((int64_t)rep * Mp + c) * Mp + k) : vzero<T>();
+  }
+  template <class Acc, int NB_>
+  __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
+        if (m >= nrows) continue;
+        const T as2 = T(2) * asum[m];
+#pragma unroll
+        for (int b = 0; b < NTCfg<T>::NB; ++b) {
+          const int n = n0 + nt_acc_col<T>(wc, b, lane);
+          if (n >= Mp) continue;
+          T v = acc[a][b][r] - as2 * W[m * Mp + n];
+          if (n < M) for (int k = 0; k < K; ++k) v += locbar[(int64_t)k * ldk + m] * U[(int64_t)k * M + n];
+          Wbar[m * Mp + n] = v;
+        }
+      }
+  }
+  __device__ __forceinline__ void finish(int64_t, int, ECtx&, char*, int, int, int) const {}
+};
+
 // (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
 template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
+  static constexpr bool A_PER_REP = false;
+  static constexpr int DEPTH = 1;
   const TN* Wbar; int64_t nrows; int M, Mp, D, kind;
   const T* LinvT;                  // [Mp][Mp], LinvT[i][j] = Linv[j][i]
   const T* Knm;                    // [nrows][Mp] solve-precision K_nm (same buffer the forward consumed)
@@ -357,7 +449,7 @@ template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const { e.s1 = 0; e.s2 = 0; }
   using AVec = TN __attribute__((ext_vector_type(Vec16<T>::N)));        // same element count, N-side element type
-  __device__ __forceinline__ AVec loadA(const ACtx& c, int i, int k, int) const {
+  __device__ __forceinline__ AVec loadA(const ACtx& c, int i, int k, int, int) const {
     AVec t;
 #pragma unroll
     for (int e = 0; e < Vec16<T>::N; ++e) t[e] = 0;

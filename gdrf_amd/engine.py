@@ -32,7 +32,8 @@ class Engine:
     """One device context for fixed (n_cap, M, K, V, D, dtype, kernel)."""
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
-                 device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False):
+                 device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
+                 store_t="auto"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -50,11 +51,12 @@ class Engine:
         self.device = torch.device("cuda", dev_index)
         torch.cuda.set_device(dev_index)
         ctx = C.c_void_p()
-        _lib.check(self.lib.gdrf_ctx_create(C.byref(ctx), dev_index, self.n_cap, self.M, self.K, self.V, self.D,
-                                            (2 if pure_fp32 else 0) if dtype == torch.float32 else 1, KERNEL_IDS[kernel]),
-                   "gdrf_ctx_create")
+        _lib.check(self.lib.gdrf_ctx_create_ex(C.byref(ctx), dev_index, self.n_cap, self.M, self.K, self.V, self.D,
+                                               (2 if pure_fp32 else 0) if dtype == torch.float32 else 1, KERNEL_IDS[kernel],
+                                               {"auto": 2, True: 1, False: 0}[store_t]), "gdrf_ctx_create_ex")
         self.pure_fp32 = bool(pure_fp32) and dtype == torch.float32
         self.ctx = ctx
+        self.stores_t = bool(self.lib.gdrf_stores_t(self.ctx))
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
         self.layout = dict(log_lengthscale=lay[0], log_variance=lay[1], log_noise=lay[2], u_loc=lay[3], phi_unc=lay[4],
@@ -194,20 +196,24 @@ class Engine:
 
     def factorize(self, force_level: Optional[int] = None) -> int:
         """jittercholesky: smallest level whose cumulative jitter lets the Cholesky factorisation succeed IN THE
-        ARRAY PRECISION (every call starts from level 0, as the reference rebuilds K_uu each time), then the
-        factor and its inverse in the solve precision at that level."""
+        ARRAY PRECISION (every call starts from level 0, as the reference rebuilds K_uu each time; up to 8 levels
+        are attempted concurrently per launch), then the factor and its inverse in the solve precision."""
         s = _stream_ptr(self.device)
         failed = C.c_int()
         level = 0 if force_level is None else force_level
         while level < self.maxjitter:
-            jt = self.jitter_total(level)
             if force_level is None:
-                _lib.check(self.lib.gdrf_probe(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jt, s), "gdrf_probe")
-                _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), s), "gdrf_chol_failed")
-                if failed.value:
-                    level += 1
+                nlev = min(4 if level == 0 else 8, self.maxjitter - level)
+                jit = (C.c_double * nlev)(*[self.jitter_total(level + l) for l in range(nlev)])
+                flags = (C.c_int * nlev)()
+                _lib.check(self.lib.gdrf_probe(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jit, nlev, flags, s), "gdrf_probe")
+                ok = [l for l in range(nlev) if not flags[l]]
+                if not ok:
+                    level += nlev
                     continue
-            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jt, s), "gdrf_factorize")
+                level += ok[0]
+            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(level), s),
+                       "gdrf_factorize")
             _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), s), "gdrf_chol_failed")
             if not failed.value:
                 self.last_jitter_level = level

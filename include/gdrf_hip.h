@@ -36,6 +36,14 @@ int gdrf_version(void);
 /* Workspaces for at most n_cap local observations.  Replaces the tensors pyro/autograd allocate
  * per step inside SVI.step (gdrf/train_script.py:365-371,467). */
 int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id);
+/* As above with an explicit choice for the backward of the variance term: GDRF_STORE_T_ON keeps T_k = W S_k
+ * (K*n_cap*M elements) from the forward so that Wbar is the triangular product sum_k diag(2 vbar_k) T_k S_k^T;
+ * GDRF_STORE_T_OFF (what gdrf_ctx_create uses) takes the dense form sum_k diag(2 vbar_k) W (S_k S_k^T): twice the
+ * MFMA flops, no extra memory, but its A operand is reused across the K topics from LDS -- measured faster on MI355X
+ * (43 vs 47 ms at the headline size).  GDRF_STORE_T_AUTO currently resolves to OFF. */
+enum { GDRF_STORE_T_OFF = 0, GDRF_STORE_T_ON = 1, GDRF_STORE_T_AUTO = 2 };
+int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id, int store_t);
+int gdrf_stores_t(const gdrf_ctx* ctx);
 void gdrf_ctx_destroy(gdrf_ctx* ctx);
 
 /* Flat unconstrained-parameter vector (the PyroParam storage of gdrf/models/sparse_gdrf.py:96-122
@@ -60,14 +68,17 @@ int gdrf_fill_eps(gdrf_ctx* ctx, uint64_t seed, uint32_t step, int64_t n_offset,
  * (gdrf/models/sparse_gdrf.py:363-372).  Synchronises the stream. */
 int gdrf_ll_const(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* out_host, void* stream);
 
-/* One attempt of jittercholesky (gdrf/models/utils.py:27-40) on kernel(inducing_points) + jitter_total*I
- * (gdrf/models/sparse_gdrf.py:327-328,382-383) in the array precision -- the precision in which the reference's
- * torch.linalg.cholesky decides whether more jitter is needed.  A non-positive pivot is reported by
- * gdrf_chol_failed(); the host then retries with the next cumulative jitter. */
-int gdrf_probe(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream);
+/* jittercholesky's retry loop (gdrf/models/utils.py:27-40) on kernel(inducing_points)
+ * (gdrf/models/sparse_gdrf.py:327-328,382-383): nlev (<= 8) attempts with the cumulative jitters
+ * jitters_host[0..nlev) factorised concurrently in ONE launch, in the array precision -- the precision in
+ * which the reference's torch.linalg.cholesky decides whether more jitter is needed.  failed_host[l] != 0 when
+ * attempt l hit a non-positive pivot; the caller takes the first success (same outcome as trying them in order).
+ * Synchronises the stream. */
+int gdrf_probe(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const double* jitters_host, int nlev,
+               int* failed_host, void* stream);
 
 /* K_uu + jitter_total*I, its Cholesky factor L and L^{-1} in the solve precision, kept in the context for
- * the calls below (reuses the probe's factor when both precisions coincide). */
+ * the calls below. */
 int gdrf_factorize(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream);
 
 /* Forward + backward over this rank's n_local observations: everything of one

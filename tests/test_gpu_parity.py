@@ -70,12 +70,16 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("store_t", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("case", CASES)
-def test_step_stages_and_grads(dtype, case):
+def test_step_stages_and_grads(dtype, case, store_t):
+    """store_t: both forms of the Wbar contraction (stored T_k, triangular; dense W B_k)."""
     case = dict(case)
     m, eps = make_oracle(dtype=dtype, jitter=1e-6 if dtype == torch.float64 else 1e-4, **case)
-    eng = engine_from_oracle(m)
+    eng = engine_from_oracle(m, store_t=store_t)
+    assert eng.stores_t == store_t
+    assert not engine_from_oracle(m).stores_t          # default: dense form (measured faster, DESIGN.md section 7)
     xs, ws, e = dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng)
     eng.loss_and_grads(xs, ws, e)
     out = eng.read_out()
