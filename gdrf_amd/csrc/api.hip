@@ -173,10 +173,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
     c->t_ts = (int64_t)GDRF_TILE * c->Mp + 1536;                                   // + 6 KB (f32): not a power of two
     c->t_bs = c->t_ts * ((n_cap + GDRF_TILE - 1) / GDRF_TILE) + 40960 + 512;
     const size_t tbytes = (size_t)K * c->t_bs * c->esz;
-    size_t fr = 0, tot = 0;
-    (void)hipMemGetInfo(&fr, &tot);
-    const bool want = store_t == GDRF_STORE_T_ON && tbytes <= ((size_t)64 << 30) && tbytes * 5 <= fr * 2 + tbytes * 5 * (fr == 0);
-    if (want) { AL(c->Tst, tbytes) }
+    if (store_t == GDRF_STORE_T_ON) { AL(c->Tst, tbytes) }
   }
   c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
   AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
@@ -292,7 +289,7 @@ template <typename T, typename TS> struct Impl {
   template <typename E>
   static int mm_nt(gdrf_ctx* c, const E* A, int64_t abs_, const E* Bt, int64_t bbs, E* Cm, int64_t cbs, E alpha, int batch,
                    hipStream_t s) {
-    MMProb<E> p{{}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
+    MMProb<E> p{{}, {}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
     dim3 grid(c->nt * nct<E>(c), batch);
     hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");
@@ -389,19 +386,19 @@ template <typename T, typename TS> struct Impl {
     {
       if ((rc = knm_solve(c, X, n, s))) return rc;
       ScopedTimer tm(c, 3, s);
-      FwdWProb<TS, T> p{{}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
+      FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
     }
     // loc = W U^T
     {
       ScopedTimer tm(c, 4, s);
-      LocProb<T> p{{}, {}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
+      LocProb<T> p{{}, {}, {}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, s, p);
     }
     // (2) tt_kn = ||S_k^T w_n||^2
     {
       ScopedTimer tm(c, 5, s);
-      FwdTProb<T> p{{}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
+      FwdTProb<T> p{{}, {}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
     }
     LAUNCHCHK("forward");
@@ -445,7 +442,7 @@ template <typename T, typename TS> struct Impl {
     // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
       ScopedTimer tm(c, 8, s);
-      BwdKnmProb<TS, T> p{{}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
+      BwdKnmProb<TS, T> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
                           c->dpart};
       const int64_t nb = rtiles * nct<TS>(c);
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");

@@ -21,6 +21,7 @@
 //   V    a_to_lds(AVec)                   conversion applied when the prefetched registers are written to LDS (so that a
 //                                         precision change does not force a wait on the loads ahead of the MFMAs)
 //   V    loadB(n0, i, k, rep, bz)
+//   int  extra_chunks(); void fill_extra(As, Bs, x, m0, n0)   problem-staged chunks multiplied after the main reduction
 //   void prepE(ectx, m0, bz)
 //   void tile_done(acc, m0, n0, bz, ectx, wr, wc, lane)
 //   void finish(m0, bz, ectx, smem, wr, wc, lane)     once per workgroup
@@ -109,22 +110,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
 #pragma unroll
       for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, kA + srow_k, rep, bz);
     };
-    auto body = [&](typename P::AVec (&ra)[C::VPT], V (&rb)[C::VPTB], int c) {
-      int kA, rep;
-      chunk_pos(c, kA, rep);
-      __syncthreads();
-      if (rep == 0 || P::A_PER_REP) {
-#pragma unroll
-        for (int i = 0; i < C::VPT; ++i) *reinterpret_cast<V*>(&As[nt_stage_row<T>(i) * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
-      __syncthreads();
-      if (c + P::DEPTH < nchunks) gload(ra, rb, c + P::DEPTH);      // refill the set just consumed
+    // multiply the staged chunk out of LDS (rep < 0: no per-row scale)
+    auto compute = [&](int rep) {
       T sc[4];
       if (P::SCALE_A) {
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) sc[t4] = scaleS[rep * GDRF_TILE + wr * 64 + t4 * 16 + lr];
+        for (int t4 = 0; t4 < 4; ++t4) sc[t4] = rep >= 0 ? scaleS[rep * GDRF_TILE + wr * 64 + t4 * 16 + lr] : T(1);
       }
       // fragments: lane (lr, lg) owns k indices lg*KG .. lg*KG+KG-1 of this chunk for row/col lr
       const T* pa = &As[(wr * 64 + lr) * C::LDK + lg * C::KG];
@@ -150,6 +141,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
             for (int b = 0; b < C::NB; ++b) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
       }
     };
+    auto body = [&](typename P::AVec (&ra)[C::VPT], V (&rb)[C::VPTB], int c) {
+      int kA, rep;
+      chunk_pos(c, kA, rep);
+      __syncthreads();
+      if (rep == 0 || P::A_PER_REP) {
+#pragma unroll
+        for (int i = 0; i < C::VPT; ++i) *reinterpret_cast<V*>(&As[nt_stage_row<T>(i) * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
+      __syncthreads();
+      if (c + P::DEPTH < nchunks) gload(ra, rb, c + P::DEPTH);      // refill the set just consumed
+      compute(rep);
+    };
     if (P::DEPTH == 1) {
       if (nchunks > 0) gload(ra0, rb0, 0);
       for (int c = 0; c < nchunks; ++c) body(ra0, rb0, c);
@@ -160,6 +165,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
         body(ra0, rb0, c);
         if (c + 1 < nchunks) body(ra1, rb1, c + 1);
       }
+    }
+    // problem-owned extra chunks (a low-rank term of the epilogue done on the matrix cores): the problem writes
+    // the two LDS tiles itself
+    for (int x = 0; x < p.extra_chunks(); ++x) {
+      __syncthreads();
+      p.fill_extra(As, Bs, x, m0, n0);
+      __syncthreads();
+      compute(-1);
     }
     p.tile_done(acc, m0, n0, bz, ectx, wr, wc, lane);
   }
@@ -179,6 +192,11 @@ template <typename T> __device__ __forceinline__ int nt_acc_col(int wc, int b, i
 template <typename T> struct NTPlainA {
   using AVec = typename Vec16<T>::type;
   __device__ __forceinline__ AVec a_to_lds(const AVec& v) const { return v; }
+};
+// default: no problem-owned extra chunks
+struct NTNoExtra {
+  __device__ __forceinline__ int extra_chunks() const { return 0; }
+  template <typename T> __device__ __forceinline__ void fill_extra(T*, T*, int, int64_t, int) const {}
 };
 
 struct NTDefaultMap {

@@ -319,7 +319,7 @@ __global__ void build_phi_kernel(const T* __restrict__ phi_unc, int K, int V, T*
 }
 
 // ---- plain batched M x M product on the NT core: C[b] = alpha * A[b] * Bt[b]^T ------------------
-template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T> {
+template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;

@@ -117,7 +117,7 @@ template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2,
 //     stores W and the per-column-tile partial of q_n = ||w_n||^2.
 // T = solve precision (f64 in the default fp32 mode: the triangular solve cancels terms ~|Linv||k| >> |w|),
 // TN = precision of the N-sized outputs (W, qpart)
-template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
+template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
@@ -180,7 +180,7 @@ template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T> {
 };
 
 // (1b) loc = W U^T on the matrix cores: Bt = zero-padded u_loc [128][Mp]; stores loc[k][n] for k < K
-template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
+template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
@@ -226,7 +226,7 @@ template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T> {
 };
 
 // (2) T_k = W S_k (never stored) -> tt[k][n] = sum_j T_k[n][j]^2 ; one workgroup walks all column tiles
-template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T> {
+template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
@@ -337,6 +337,19 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(Bm + ((int64_t)rep * Mp + c) * Mp + k) : vzero<T>();
   }
+  // rank-K epilogue term locbar^T U as extra MFMA chunk(s): As[row][kk] = locbar[k][m0+row], Bs[col][kk] = U[k][n0+col]
+  __device__ __forceinline__ int extra_chunks() const { return (K + NTCfg<T>::BK - 1) / NTCfg<T>::BK; }
+  __device__ __forceinline__ void fill_extra(T* As, T* Bs, int x, int64_t m0, int n0) const {
+    constexpr int BK = NTCfg<T>::BK, LDK = NTCfg<T>::LDK, CW = NTCfg<T>::CW;
+    for (int e = threadIdx.x; e < GDRF_TILE * BK; e += 256) {
+      const int kk = e / GDRF_TILE, row = e - kk * GDRF_TILE, k = x * BK + kk;
+      As[row * LDK + kk] = (k < K && m0 + row < nrows) ? locbar[(int64_t)k * ldk + m0 + row] : T(0);
+    }
+    for (int e = threadIdx.x; e < CW * BK; e += 256) {
+      const int kk = e / CW, col = e - kk * CW, k = x * BK + kk;
+      Bs[col * LDK + kk] = (k < K && n0 + col < M) ? U[(int64_t)k * M + n0 + col] : T(0);
+    }
+  }
   template <class Acc, int NB_>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
 #pragma unroll
@@ -351,7 +364,6 @@ template <typename T> struct BwdWbarProb : NTXcdMap, NTPlainA<T> {
           const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (n >= Mp) continue;
           T v = acc[a][b][r] - as2 * W[m * Mp + n];
-          if (n < M) for (int k = 0; k < K; ++k) v += locbar[(int64_t)k * ldk + m] * U[(int64_t)k * M + n];
           Wbar[m * Mp + n] = v;
         }
       }
@@ -401,6 +413,19 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(S + ((int64_t)rep * Mp + c) * Mp + k) : vzero<T>();
   }
+  // rank-K epilogue term locbar^T U as extra MFMA chunk(s): As[row][kk] = locbar[k][m0+row], Bs[col][kk] = U[k][n0+col]
+  __device__ __forceinline__ int extra_chunks() const { return (K + NTCfg<T>::BK - 1) / NTCfg<T>::BK; }
+  __device__ __forceinline__ void fill_extra(T* As, T* Bs, int x, int64_t m0, int n0) const {
+    constexpr int BK = NTCfg<T>::BK, LDK = NTCfg<T>::LDK, CW = NTCfg<T>::CW;
+    for (int e = threadIdx.x; e < GDRF_TILE * BK; e += 256) {
+      const int kk = e / GDRF_TILE, row = e - kk * GDRF_TILE, k = x * BK + kk;
+      As[row * LDK + kk] = (k < K && m0 + row < nrows) ? locbar[(int64_t)k * ldk + m0 + row] : T(0);
+    }
+    for (int e = threadIdx.x; e < CW * BK; e += 256) {
+      const int kk = e / CW, col = e - kk * CW, k = x * BK + kk;
+      Bs[col * LDK + kk] = (k < K && n0 + col < M) ? U[(int64_t)k * M + n0 + col] : T(0);
+    }
+  }
   template <class Acc, int NB_>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx&, int wr, int wc, int lane) const {
 #pragma unroll
@@ -415,7 +440,6 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
           const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (n >= Mp) continue;
           T v = acc[a][b][r] - as2 * W[m * Mp + n];
-          if (n < M) for (int k = 0; k < K; ++k) v += locbar[(int64_t)k * ldk + m] * U[(int64_t)k * M + n];
           Wbar[m * Mp + n] = v;
         }
       }
@@ -424,7 +448,7 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
 };
 
 // (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
-template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap {
+template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
