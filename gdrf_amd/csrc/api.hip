@@ -182,7 +182,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->erows_grid_cap = 1024;
   AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
   const int64_t rtiles = (n_cap + GDRF_TILE - 1) / GDRF_TILE;
-  c->dpart_len = std::max<int64_t>((rtiles * ((c->Mp + 63) / 64) + 16) * 2, 8192);
+  c->dpart_len = std::max<int64_t>(((rtiles + 8) * ((c->Mp + 63) / 64) + 16) * 2, 8192);
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
@@ -387,7 +387,7 @@ template <typename T, typename TS> struct Impl {
       if ((rc = knm_solve(c, X, n, s))) return rc;
       ScopedTimer tm(c, 3, s);
       FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
-      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3((unsigned)(rtiles * nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
     }
     // loc = W U^T
     {
@@ -444,7 +444,7 @@ template <typename T, typename TS> struct Impl {
       ScopedTimer tm(c, 8, s);
       BwdKnmProb<TS, T> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
                           c->dpart};
-      const int64_t nb = rtiles * nct<TS>(c);
+      const int64_t nb = nt_xcd_row_grid(rtiles, nct<TS>(c));
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
       hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 2, redd + 4);

@@ -217,6 +217,19 @@ struct NTXcdMap {
   }
 };
 
+// XCD-aware map that keeps ALL column tiles of a row tile on one XCD, dispatched back to back: their A operand (the
+// row tile's slab, cold in HBM) is then fetched once into that XCD's L2 and shared, instead of once per column tile.
+// Grid: nt_xcd_row_grid(rtiles, nct); padding blocks get rtile >= rtiles.
+inline unsigned nt_xcd_row_grid(int64_t rtiles, int nct) { return (unsigned)(8 * nct * ((rtiles + 7) / 8)); }
+struct NTXcdRowMap {
+  __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
+    if (loopc) { rtile = bid; ct = 0; return; }
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    rtile = (int64_t)(idx / (unsigned)nct) * 8 + xcd;
+    ct = (int)(idx % (unsigned)nct);
+  }
+};
+
 // XCD-aware map for TRIANGULAR reductions, where column tile ct costs (ct+1) units: column tiles are paired
 // (ct, nct-1-ct) so that every XCD alternates a light and a heavy tile (equal work per XCD) while still keeping
 // only two tiles' B panels in its L2.  The XCDs that share a pair deal the row tiles round-robin.

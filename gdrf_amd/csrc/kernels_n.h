@@ -117,7 +117,7 @@ template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2,
 //     stores W and the per-column-tile partial of q_n = ||w_n||^2.
 // T = solve precision (f64 in the default fp32 mode: the triangular solve cancels terms ~|Linv||k| >> |w|),
 // TN = precision of the N-sized outputs (W, qpart)
-template <typename T, typename TN> struct FwdWProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
+template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
@@ -448,7 +448,7 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
 };
 
 // (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
-template <typename T, typename TN> struct BwdKnmProb : NTDefaultMap, NTNoExtra {
+template <typename T, typename TN> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
