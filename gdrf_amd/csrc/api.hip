@@ -398,8 +398,8 @@ template <typename T, typename TS> struct Impl {
     // (2) tt_kn = ||S_k^T w_n||^2
     {
       ScopedTimer tm(c, 5, s);
-      FwdTProb<T> p{{}, {}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
-      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)rtiles, K), dim3(256), C::LDS_BYTES, s, p);
+      FwdTProb<T> p{{K}, {}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
+      hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)(8 * K * ((rtiles + 7) / 8))), dim3(256), C::LDS_BYTES, s, p);
     }
     LAUNCHCHK("forward");
     // per-row ELBO terms and row-local backward

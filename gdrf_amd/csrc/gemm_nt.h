@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
   p.map_block(blockIdx.x, nct, loopc, rtile, ct_first);
   const int ct_last = loopc ? nct : ct_first + 1;
   const int64_t m0 = rtile * GDRF_TILE;
-  const int bz = blockIdx.y;
+  const int bz = p.batch_index(blockIdx.x, blockIdx.y);
   const int R = p.a_reuse();
 
   typename P::ACtx actx;
@@ -200,6 +200,7 @@ struct NTNoExtra {
 };
 
 struct NTDefaultMap {
+  __device__ __forceinline__ int batch_index(unsigned, unsigned by) const { return (int)by; }
   __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
     if (loopc) { rtile = bid; ct = 0; } else { rtile = bid / nct; ct = (int)(bid % nct); }
   }
@@ -208,6 +209,7 @@ struct NTDefaultMap {
 // XCD works on ONE column tile at a time so that tile's B panels stay resident in its 4 MiB L2, and
 // the row tiles are dealt round-robin.  Bijective whenever nct divides 8; falls back otherwise.
 struct NTXcdMap {
+  __device__ __forceinline__ int batch_index(unsigned, unsigned by) const { return (int)by; }
   __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
     if (loopc) { rtile = bid; ct = 0; return; }
     if (nct > 8 || (8 % nct) != 0 || (gridDim.x % 8u) != 0) { rtile = bid / nct; ct = (int)(bid % nct); return; }
@@ -222,11 +224,24 @@ struct NTXcdMap {
 // Grid: nt_xcd_row_grid(rtiles, nct); padding blocks get rtile >= rtiles.
 inline unsigned nt_xcd_row_grid(int64_t rtiles, int nct) { return (unsigned)(8 * nct * ((rtiles + 7) / 8)); }
 struct NTXcdRowMap {
+  __device__ __forceinline__ int batch_index(unsigned, unsigned by) const { return (int)by; }
   __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
     if (loopc) { rtile = bid; ct = 0; return; }
     const unsigned xcd = bid & 7u, idx = bid >> 3;
     rtile = (int64_t)(idx / (unsigned)nct) * 8 + xcd;
     ct = (int)(idx % (unsigned)nct);
+  }
+};
+
+// 1-D grid over (row tile, batch) for workgroups that walk all their column tiles themselves: the nbatch workgroups of
+// a row tile (one per topic) run back to back on one XCD and share that row tile's A slab through its L2.
+// Grid: 8 * nbatch * ceil(rtiles / 8).
+struct NTXcdRowBatchMap {
+  int nbatch;
+  __device__ __forceinline__ int batch_index(unsigned bid, unsigned) const { return (int)((bid >> 3) % (unsigned)nbatch); }
+  __device__ __forceinline__ void map_block(unsigned bid, int, bool, int64_t& rtile, int& ct) const {
+    rtile = (int64_t)((bid >> 3) / (unsigned)nbatch) * 8 + (bid & 7u);
+    ct = 0;
   }
 };
 
@@ -241,6 +256,7 @@ inline unsigned nt_xcd_pair_grid(int64_t rtiles, int nct) {
   return (unsigned)(16 * ((rtiles + nper - 1) / nper));
 }
 struct NTXcdPairMap {
+  __device__ __forceinline__ int batch_index(unsigned, unsigned by) const { return (int)by; }
   __device__ __forceinline__ void map_block(unsigned bid, int nct, bool loopc, int64_t& rtile, int& ct) const {
     if (loopc) { rtile = bid; ct = 0; return; }
     if (!nt_xcd_pair_ok(nct)) { rtile = bid / nct; ct = (int)(bid % nct); return; }

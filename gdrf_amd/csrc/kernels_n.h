@@ -226,7 +226,7 @@ template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
 };
 
 // (2) T_k = W S_k (never stored) -> tt[k][n] = sum_j T_k[n][j]^2 ; one workgroup walks all column tiles
-template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
+template <typename T> struct FwdTProb : NTXcdRowBatchMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
@@ -271,7 +271,7 @@ template <typename T> struct FwdTProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
       for (int b = 0; b < NTCfg<T>::NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) e.rs[a][r] += acc[a][b][r] * acc[a][b][r];
-    if (Tst) {
+    if (Tst && m0 < nrows) {          // padding workgroups of the rounded-up grid own no tile
       constexpr int BK = NTCfg<T>::BK;
       T* base = Tst + (int64_t)bz * t_bs + (m0 / GDRF_TILE) * t_ts;     // this row tile's blocks
 #pragma unroll
