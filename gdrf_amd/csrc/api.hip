@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -344,9 +345,15 @@ template <typename T, typename TS> struct Impl {
     const int VE = Vec16<T>::N;
     const int vpr = (c->M + VE - 1) / VE, rpp = vpr <= 256 ? 256 / vpr : 1;
     int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    int64_t cap = 256 * 64;          // swept on MI355X (tools/knm_sweep.py): 2048 blocks 0.60-0.65 of HBM peak, 16384 0.67-0.79
+    if (const char* e = getenv("GDRF_KNM_BLOCKS")) cap = atoll(e);
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((knm_kernel<T, T, true>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D, c->kind, c->hyp, out, ldo);
+    const char* plain = getenv("GDRF_KNM_PLAIN_STORES");
+    if (plain && plain[0] == '1')
+      hipLaunchKernelGGL((knm_kernel<T, T, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D, c->kind, c->hyp, out, ldo);
+    else
+      hipLaunchKernelGGL((knm_kernel<T, T, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, Z, c->M, c->D, c->kind, c->hyp, out, ldo);
     LAUNCHCHK("knm");
     return 0;
   }
@@ -357,7 +364,7 @@ template <typename T, typename TS> struct Impl {
     const int VE = Vec16<TS>::N;
     const int vpr = (c->Mp + VE - 1) / VE, rpp = vpr <= 256 ? 256 / vpr : 1;
     int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((knm_kernel<TS, T, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, (const TS*)Q(c->Zs), c->M, c->D, c->kind,
                        c->hyp, Q(c->Knm), (int64_t)c->Mp);

@@ -28,7 +28,7 @@ template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T va
 
 // T: output / arithmetic type, TX: type of X, FAST: v_exp_f32-based exponential (roofline kernel) or exact exp
 // (the solve-precision copy of K_nm that feeds W = K_nm L^-T).  Columns M..ldo-1 of every row are written as zeros.
-template <typename T, typename TX, bool FAST>
+template <typename T, typename TX, bool FAST, bool NT = true>
 __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int64_t N, const T* __restrict__ Z, int M, int D,
                                                   int kind, const Hyper* __restrict__ h, T* __restrict__ out, int64_t ldo) {
   using V = typename Vec16<T>::type;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
           o[e] = (i0 + e < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var) : cov_from_r2<T>(kind, r2 * ils2, var)) : T(0);
         }
         T* orow = out + row * ldo;
-        if (vec_ok) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0));
+        if (vec_ok) { if (NT) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0)); else *reinterpret_cast<V*>(orow + i0) = o; }
         else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) orow[i0 + e] = o[e];
       }
     }

@@ -129,3 +129,18 @@ def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
     assert np.allclose(r0["losses"], ref, rtol=1e-10)                      # Philox keyed by the global row: same eps
     assert torch.equal(r0["params"], r1["params"])
     assert (r0["params"] - model._engine.params.cpu()).abs().max() < 1e-9
+
+
+def test_train_driver_full_batch_and_streaming():
+    from gdrf_amd.train import train
+    xs, ws, _ = synth_circles(24, 16, 20, 4, seed=2)
+    out = train(xs=xs, ws=ws, dimensions=2, epochs=25, num_topics=4, num_inducing_points=[6, 4], inducing_initialization_method="grid",
+                kernel_lengthscale=0.2, optimizer_type="adamw", optimizer_lr=0.01, jitter=1e-6)
+    h = out["history"]
+    assert h.shape == (25, 4) and np.isfinite(h).all() and h[-1, 1] < h[0, 1]          # perplexity improves
+    xs1, ws1, _ = synth_circles(60, 1, 12, 3, seed=4, one_d=True)
+    for mode in ("uniform_now", "exp"):
+        out = train(xs=xs1, ws=ws1, dimensions=1, num_topics=3, num_inducing_points=8, inducing_initialization_method="grid",
+                    streaming_inference=mode, streaming_size=3, kernel_lengthscale=0.2, optimizer_lr=0.01, jitter=1e-6,
+                    perplexity_every=20)
+        assert out["history"].shape[0] == 60 and np.isfinite(out["history"][:, 0]).all()

@@ -110,3 +110,24 @@ def test_normalise_index_matches_train_script():
     xs, ws, topic = synth_circles(20, 10, 30, 5, seed=1)
     assert xs.shape == (200, 2) and ws.shape == (200, 30) and ws.dtype == np.int32
     assert ws.sum(1).min() >= 30 and ws.sum(1).max() < 300 and xs.min() == 0 and xs.max() == 1
+
+
+@pytest.mark.parametrize("mode", ["uniform", "now", "exp", "uniform_now", "exp_now", "uniform_exp"])
+def test_streaming_probabilities_follow_train_script(mode):
+    """gdrf/train_script.py:406-450: each schedule, normalised; 'now' always picks the newest observation."""
+    import numpy as np
+    from gdrf_amd.train import streaming_probabilities
+    for n in (1, 2, 7):
+        p = streaming_probabilities(mode, n, streaming_weight=0.1, streaming_exp=1.0)
+        assert p.shape == (n,) and abs(p.sum() - 1) < 1e-12 and (p >= 0).all()
+        if mode == "now":
+            assert p[-1] == 1.0
+        if mode in ("exp", "exp_now", "uniform_now") and n > 1:
+            assert p[-1] == p.max()
+        if mode == "uniform":
+            assert np.allclose(p, 1.0 / n)
+    if mode == "uniform_now":
+        p = streaming_probabilities(mode, 4, streaming_weight=0.2)
+        assert np.allclose(p, [0.05, 0.05, 0.05, 0.85])
+    with pytest.raises(ValueError):
+        streaming_probabilities("sometimes", 3)
