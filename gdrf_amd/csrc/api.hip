@@ -60,6 +60,8 @@ struct gdrf_ctx {
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
   double* alpha_dev; double lgam_const;
   Hyper* hyp; int* flag;
+  hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
+  hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join;
   std::vector<void*> allocs;
   // optional per-kernel HIP-event timing (gdrf_set_timing): events recorded on the launch stream
   int timing;
@@ -143,7 +145,8 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->ssz = dtype == GDRF_F32_PURE ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
-  c->pK = c->pL = nullptr; c->Tst = nullptr;
+  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr;
+  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -189,6 +192,8 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
   AL(c->hyp, sizeof(Hyper)) AL(c->flag, 64)
 #undef AL
+  HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(hipMemset(c->flag, 0, 64));
   HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
   std::vector<double> a((size_t)K * V, 1.0);
@@ -202,6 +207,8 @@ void gdrf_ctx_destroy(gdrf_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& t : c->tev) { (void)hipEventDestroy(t.second.first); (void)hipEventDestroy(t.second.second); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join}) if (e) (void)hipEventDestroy(e);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 
@@ -396,12 +403,15 @@ template <typename T, typename TS> struct Impl {
       FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
     }
-    // loc = W U^T
+    // loc = W U^T, on the side stream beside fwd_t (both only read W)
+    HIPCHK(hipEventRecord(c->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     {
-      ScopedTimer tm(c, 4, s);
+      ScopedTimer tm(c, 4, c->side);
       LocProb<T> p{{}, {}, {}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
-      hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, c->side, p);
     }
+    HIPCHK(hipEventRecord(c->ev_loc, c->side));
     // (2) tt_kn = ||S_k^T w_n||^2
     {
       ScopedTimer tm(c, 5, s);
@@ -409,6 +419,7 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)(8 * K * ((rtiles + 7) / 8))), dim3(256), C::LDS_BYTES, s, p);
     }
     LAUNCHCHK("forward");
+    HIPCHK(hipStreamWaitEvent(s, c->ev_loc, 0));
     // per-row ELBO terms and row-local backward
     int egrid;
     {
@@ -446,6 +457,30 @@ template <typename T, typename TS> struct Impl {
         hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarProb<T>>), grid, dim3(256), lds, s, p);
       }
     }
+    // Wbar is ready: G^T = W^T Wbar and ubar = locbar W go to the side stream, where they fill the last-round tails of
+    // bwd_knm and the A_k contraction on the main stream
+    HIPCHK(hipEventRecord(c->ev_fork2, s));
+    HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork2, 0));
+    {
+      hipStream_t ss = c->side;
+      const int BR = TNCfg<T>::BR;
+      const int ns = std::min(tn_nsplit(c, n, BR), c->nsplit_cap);
+      const int64_t rps = round_up((n + ns - 1) / ns, BR);
+      T* slab_gt = P(c->slab) + (int64_t)c->nsplit_cap * K * mm;           // the (K+1)-th batch region of the slab buffer
+      TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, slab_gt, 1, ns};
+      { ScopedTimer tm(c, 10, ss);
+        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, ss, b); }
+      { ScopedTimer tm(c, 11, ss);
+        dim3 gr1((Mp + 255) / 256, Mp, 1);
+        hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, ss, (const T*)slab_gt, ns, 1, Mp, 0, redT + roff(c, 3)); }
+      ScopedTimer tm(c, 12, ss);
+      const int64_t nb = (n + 2047) / 2048;
+      hipLaunchKernelGGL(ubar_part_kernel<T>, dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, ss, P(c->W), n, Mp, K, P(c->locbar),
+                         ldk, (int64_t)2048, P(c->ubar_part));
+      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, ss, P(c->ubar_part), nb, (int64_t)K * Mp,
+                         redT + roff(c, 0));
+    }
+    HIPCHK(hipEventRecord(c->ev_join, c->side));
     // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
       ScopedTimer tm(c, 8, s);
@@ -468,22 +503,8 @@ template <typename T, typename TS> struct Impl {
       { ScopedTimer tm(c, 11, s);
         dim3 gr((Mp + 255) / 256, Mp, K);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2)); }
-      TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, P(c->slab), 1, ns};
-      { ScopedTimer tm(c, 10, s);
-        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, b); }
-      { ScopedTimer tm(c, 11, s);
-        dim3 gr1((Mp + 255) / 256, Mp, 1);
-        hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, s, P(c->slab), ns, 1, Mp, 0, redT + roff(c, 3)); }
     }
-    // (6) ubar
-    {
-      ScopedTimer tm(c, 12, s);
-      const int64_t nb = (n + 2047) / 2048;
-      hipLaunchKernelGGL(ubar_part_kernel<T>, dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, s, P(c->W), n, Mp, K, P(c->locbar),
-                         ldk, (int64_t)2048, P(c->ubar_part));
-      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, s, P(c->ubar_part), nb, (int64_t)K * Mp,
-                         redT + roff(c, 0));
-    }
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     LAUNCHCHK("reductions");
     return 0;
   }
