@@ -136,7 +136,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   if (K > GDRF_KMAX) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 32 not supported");
   if (D > GDRF_DMAX) return fail(-1, "gdrf_ctx_create", "more than 4 input dimensions not supported");
   if (dtype != GDRF_F32 && dtype != GDRF_F64 && dtype != GDRF_F32_PURE) return fail(-1, "gdrf_ctx_create", "dtype");
-  if (kernel_id != GDRF_RBF && kernel_id != GDRF_MATERN52) return fail(-1, "gdrf_ctx_create", "kernel_id");
+  if (kernel_id < GDRF_RBF || kernel_id > GDRF_EXPONENTIAL) return fail(-1, "gdrf_ctx_create", "kernel_id");
   HIPCHK(hipSetDevice(device));
   gdrf_ctx* c = new gdrf_ctx();
   c->dev = device; c->M = M; c->Mp = (int)round_up(M, GDRF_MPAD); c->K = K; c->V = V; c->D = D;

@@ -73,9 +73,12 @@ template <> __device__ __forceinline__ double t_eps<double>() { return 2.2204460
 // kind 0 = RBF, 1 = Matern52.  r2 is the squared distance scaled by 1/lengthscale^2.
 struct KParams { double inv_ls2; double var; };     // device-side hyper-parameters (double, cast per use)
 
+// kind: 0 RBF, 1 Matern52, 2 Matern32, 3 Exponential  (pyro.contrib.gp.kernels.isotropic)
 template <typename T> __device__ __forceinline__ T cov_from_r2(int kind, T r2, T var) {
   if (kind == 0) return var * t_exp<T>(T(-0.5) * r2);
   const T r = t_sqrt<T>(r2 + T(1e-12));
+  if (kind == 3) return var * t_exp<T>(-r);
+  if (kind == 2) { const T a = T(1.73205080756887729353) * r; return var * (T(1) + a) * t_exp<T>(-a); }
   const T a = T(2.23606797749978969641) * r;
   return var * (T(1) + a + (T(5) / T(3)) * r * r) * t_exp<T>(-a);
 }
@@ -83,6 +86,8 @@ template <typename T> __device__ __forceinline__ T cov_from_r2(int kind, T r2, T
 template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T r2, T var) {
   if (kind == 0) return k * r2;
   const T r = t_sqrt<T>(r2 + T(1e-12));
+  if (kind == 3) return k * (r2 / r);
+  if (kind == 2) { const T a = T(1.73205080756887729353) * r; return var * t_exp<T>(-a) * a * T(1.73205080756887729353) * (r2 / r); }
   const T a = T(2.23606797749978969641) * r;
   return var * t_exp<T>(-a) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
 }
@@ -90,6 +95,8 @@ template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T 
 template <typename T> __device__ __forceinline__ T dcov_dlogls_from_k(int kind, T k, T r2) {
   if (kind == 0) return k * r2;
   const T r = t_sqrt<T>(r2 + T(1e-12));
+  if (kind == 3) return k * (r2 / r);
+  if (kind == 2) { const T a = T(1.73205080756887729353) * r; return k / (T(1) + a) * a * T(1.73205080756887729353) * (r2 / r); }
   const T a = T(2.23606797749978969641) * r;
   return k / (T(1) + a + (T(5) / T(3)) * r * r) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
 }

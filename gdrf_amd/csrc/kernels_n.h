@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
 template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var) { return cov_from_r2<T>(kind, r2, var); }
 template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2, float var) {
   if (kind == 0) return var * __expf(-0.5f * r2);
-  const float r = sqrtf(r2 + 1e-12f), a = 2.2360679775f * r;
+  const float r = sqrtf(r2 + 1e-12f);
+  if (kind == 3) return var * __expf(-r);
+  if (kind == 2) { const float a3 = 1.7320508076f * r; return var * (1.0f + a3) * __expf(-a3); }
+  const float a = 2.2360679775f * r;
   return var * (1.0f + a + (5.0f / 3.0f) * r * r) * __expf(-a);
 }
 

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-KERNEL_IDS = {"rbf": 0, "matern52": 1}
+KERNEL_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3}
 OPT_MODES = {"adam": 0, "adamw": 1, "clippedadam": 2}
 
 _WS_IDS = dict(W=0, Wbar=1, q=2, loc=3, tt=4, vbar=5, locbar=6, asum=7, Kuu=8, L=9, Linv=10, S=11, B=12, phi=13,
@@ -229,13 +229,26 @@ class Engine:
         returns nothing host-side; call read_out() for the loss."""
         self._chk_rows(xs, ws)
         n = xs.shape[0]
-        if eps.shape != (self.K, n) or eps.dtype != self.dtype or not eps.is_contiguous() or eps.device != self.device:
-            raise ValueError(f"eps must be a contiguous ({self.K},{n}) {self.dtype} tensor on {self.device}")
+        if eps.dim() == 2:
+            eps = eps.unsqueeze(0)
+        P = eps.shape[0]                          # particles (Trace_ELBO num_particles): the estimator is their mean
+        if tuple(eps.shape[1:]) != (self.K, n) or eps.dtype != self.dtype or not eps.is_contiguous() or eps.device != self.device:
+            raise ValueError(f"eps must be a contiguous ([P,]{self.K},{n}) {self.dtype} tensor on {self.device}")
         s = _stream_ptr(self.device)
         self.factorize(force_level)
-        _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps.data_ptr(), n, self.Z.data_ptr(),
-                                            self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
-                   "gdrf_step_local")
+        for p in range(P):
+            _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n, self.Z.data_ptr(),
+                                                self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
+                       "gdrf_step_local")
+            if P > 1:                             # every payload entry is linear in the per-particle sums
+                if p == 0:
+                    acc_T, acc_d = self.red_T.clone(), self.red_d.clone()
+                else:
+                    acc_T += self.red_T
+                    acc_d += self.red_d
+        if P > 1:
+            self.red_T.copy_(acc_T / P)
+            self.red_d.copy_(acc_d / P)
         llc = self.ll_const(ws) if ll_const is None else ll_const
         ng = float(n if n_global is None else n_global)
         if self._distributed():

@@ -17,9 +17,9 @@ from .poutine import ScaledFn
 class _ELBO:
     def __init__(self, num_particles: int = 1, max_plate_nesting: int = float("inf"), vectorize_particles: bool = False,
                  **kwargs):
-        if int(num_particles) != 1:
-            raise NotImplementedError("num_particles > 1 (SURVEY.md 8(f) item 4)")
-        self.num_particles = 1
+        if int(num_particles) < 1:
+            raise ValueError("num_particles must be >= 1")
+        self.num_particles = int(num_particles)
         self.max_plate_nesting = max_plate_nesting
         self.vectorize_particles = vectorize_particles
 
@@ -80,10 +80,7 @@ class SVI:
         eng = model._engine_for(xs_s.shape[0])
         self.optim._bind(eng)
         n = xs_s.shape[0]
-        if eps is None:
-            eps = eng.fill_eps(model.rng_seed, self.steps_taken, self.row_offset, n)
-        else:
-            eps = torch.as_tensor(eps).to(device=eng.device, dtype=eng.dtype).contiguous()
+        eps = self._eps(eng, eps, n)
         eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale)
         self.optim._step()
         out = eng.read_out()
@@ -99,9 +96,20 @@ class SVI:
         xs_s, ws_d = model._prepare_inputs(xs, ws)
         eng = model._engine_for(xs_s.shape[0])
         n = xs_s.shape[0]
-        if eps is None:
-            eps = eng.fill_eps(model.rng_seed, self.steps_taken, self.row_offset, n)
-        else:
-            eps = torch.as_tensor(eps).to(device=eng.device, dtype=eng.dtype).contiguous()
-        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale)
+        eng.loss_and_grads(xs_s, ws_d, self._eps(eng, eps, n), n_global=1.0 / self.scale)
         return float(eng.read_out()["loss"])
+
+    def _eps(self, eng, eps, n):
+        """(P, K, n) standard normals: injected, or Philox keyed by (seed; global row, topic, step * P + particle)."""
+        P = self.loss.num_particles
+        if eps is not None:
+            eps = torch.as_tensor(eps).to(device=eng.device, dtype=eng.dtype).contiguous()
+            if eps.dim() == 2:
+                eps = eps.unsqueeze(0)
+            if eps.shape[0] != P:
+                raise ValueError(f"eps carries {eps.shape[0]} particles, the objective has num_particles={P}")
+            return eps
+        out = torch.empty(P, eng.K, n, dtype=eng.dtype, device=eng.device)
+        for p in range(P):
+            eng.fill_eps(self.gdrf.rng_seed, self.steps_taken * P + p, self.row_offset, n, out=out[p])
+        return out

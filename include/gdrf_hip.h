@@ -8,7 +8,7 @@
  * Conventions: every function returns 0 on success, < 0 on a HIP/argument error (message from
  * gdrf_last_error()); pointers named *_dev are borrowed device pointers that the caller keeps
  * alive until the stream has been synchronised; `stream` is a hipStream_t passed as void*;
- * no exceptions cross the ABI; one host thread per context.  kernel_id: 0 = RBF, 1 = Matern52.
+ * no exceptions cross the ABI; one host thread per context.  kernel_id: 0 RBF, 1 Matern52, 2 Matern32, 3 Exponential.
  * dtype fixes the element type of every "void*" real array below:
  *   GDRF_F32 (0)      float arrays.  The K-fold contractions run on f32 MFMA; the ill-conditioned pieces (K_uu, its
  *                     Cholesky factor and inverse, the solve W = K_nm L^-T, its backward and the M x M epilogue) run
@@ -26,7 +26,7 @@ extern "C" {
 typedef struct gdrf_ctx gdrf_ctx;
 
 enum { GDRF_F32 = 0, GDRF_F64 = 1, GDRF_F32_PURE = 2 };
-enum { GDRF_RBF = 0, GDRF_MATERN52 = 1 };
+enum { GDRF_RBF = 0, GDRF_MATERN52 = 1, GDRF_MATERN32 = 2, GDRF_EXPONENTIAL = 3 };
 enum { GDRF_ADAM = 0, GDRF_ADAMW = 1, GDRF_CLIPPED_ADAM = 2 };
 enum { GDRF_PRED_LOC = 0, GDRF_PRED_TOPIC_PROBS = 1, GDRF_PRED_WORD_PROBS = 2, GDRF_PRED_PERPLEXITY = 3 };
 

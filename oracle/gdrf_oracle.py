@@ -61,10 +61,15 @@ def kernel_matrix(kind: str, X: torch.Tensor, Z: torch.Tensor, lengthscale, vari
     r2 = square_scaled_dist(X, Z, lengthscale)
     if kind == "rbf":
         return variance * torch.exp(-0.5 * r2)
+    r = (r2 + 1e-12).sqrt()
     if kind == "matern52":
-        r = (r2 + 1e-12).sqrt()
         s5r = SQRT5 * r
         return variance * (1 + s5r + (5.0 / 3.0) * r ** 2) * torch.exp(-s5r)
+    if kind == "matern32":
+        s3r = 3.0 ** 0.5 * r
+        return variance * (1 + s3r) * torch.exp(-s3r)
+    if kind == "exponential":
+        return variance * torch.exp(-r)
     raise ValueError(f"unknown kernel {kind}")
 
 
@@ -326,6 +331,11 @@ def _np_kernel(kind, X, Z, ls, var):
     if kind == "rbf":
         return var * np.exp(-0.5 * r2), r2
     r = np.sqrt(r2 + 1e-12)
+    if kind == "exponential":
+        return var * np.exp(-r), r2
+    if kind == "matern32":
+        a = 3.0 ** 0.5 * r
+        return var * (1 + a) * np.exp(-a), r2
     a = SQRT5 * r
     return var * (1 + a + (5.0 / 3.0) * r * r) * np.exp(-a), r2
 
@@ -334,6 +344,11 @@ def _np_dk_dlogls(kind, k, r2, var):
     if kind == "rbf":
         return k * r2
     r = np.sqrt(r2 + 1e-12)
+    if kind == "exponential":
+        return k * (r2 / r)
+    if kind == "matern32":
+        a = 3.0 ** 0.5 * r
+        return var * np.exp(-a) * a * 3.0 ** 0.5 * (r2 / r)
     a = SQRT5 * r
     return var * np.exp(-a) * (a / 3.0) * (1 + a) * SQRT5 * (r2 / r)
 

@@ -28,7 +28,7 @@ def _aux(m, eps, level):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("kind", ["rbf", "matern52", "matern32", "exponential"])
 @pytest.mark.parametrize("shape", [(16, 9, (4, 3)), (37, 5, (5, 5)), (300, 1, (40,))])
 def test_knm(dtype, kind, shape):
     W, H, npts = shape
@@ -67,6 +67,8 @@ CASES = [
     dict(kind="matern52", W=23, H=11, V=7, K=3, n_points=(6, 6)),     # N=253 (ragged tiles), M=36
     dict(kind="rbf", W=301, H=1, V=50, K=10, n_points=(160,), one_d=True, lengthscale=0.005),   # M=160: 2 column tiles
     dict(kind="rbf", W=20, H=20, V=12, K=1, n_points=(12, 12), lengthscale=0.05),       # K=1, M=144
+    dict(kind="matern32", W=19, H=13, V=9, K=3, n_points=(5, 4)),
+    dict(kind="exponential", W=19, H=13, V=9, K=3, n_points=(5, 4)),
 ]
 
 
@@ -178,3 +180,23 @@ def test_fill_eps_is_sharding_invariant_and_standard_normal():
     x = full.double().cpu().numpy().ravel()
     assert abs(x.mean()) < 5e-3 and abs(x.std() - 1) < 5e-3
     assert abs((x ** 4).mean() - 3.0) < 0.05
+
+
+def test_multiple_particles_average_the_estimator():
+    """Trace_ELBO(num_particles=P, vectorize_particles=True): loss and gradient are the mean over P noise draws."""
+    m, _ = make_oracle(dtype=torch.float64, jitter=1e-6)
+    eng = engine_from_oracle(m)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    g = torch.Generator().manual_seed(9)
+    eps = torch.randn(3, m.K, m.N, generator=g, dtype=torch.float64)
+    losses, grads = [], []
+    for p in range(3):
+        l, gr = m.loss_and_grads(eps[p])
+        losses.append(l); grads.append(gr)
+    eng.loss_and_grads(xs, ws, dev(eps, eng))
+    out = eng.read_out()
+    assert abs(out["loss"] - np.mean(losses)) < LOSS_TOL_VS_TORCH * abs(np.mean(losses))
+    gv = eng.named_views(eng.grads)
+    for name in eng.PARAM_NAMES:
+        ref = sum(gr[name] for gr in grads).double().numpy() / 3
+        assert relerr(gv[name].cpu().numpy(), ref) < 1e-7, name

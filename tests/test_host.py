@@ -42,8 +42,9 @@ def test_kernel_registry_and_arguments():
     k = KERNEL_DICT["rbf"](input_dim=2, lengthscale=torch.tensor(0.1), variance=torch.tensor(25.0))
     assert isinstance(k, RBF) and k.to("cuda:0") is k and abs(float(k.lengthscale) - 0.1) < 1e-7
     assert isinstance(KERNEL_DICT["matern52"](input_dim=1), Matern52)
+    assert KERNEL_DICT["matern32"](input_dim=1).kernel_id == 2 and KERNEL_DICT["exponential"](input_dim=1).kernel_id == 3
     with pytest.raises(NotImplementedError):
-        KERNEL_DICT["matern32"](input_dim=1)
+        KERNEL_DICT["rationalquadratic"](input_dim=1)
     with pytest.raises(ValueError):
         RBF(2, lengthscale=torch.tensor(-1.0))
 
@@ -65,8 +66,9 @@ def test_objectives_and_scale_wrapper():
     from gdrf_amd import poutine
     from gdrf_amd.infer import OBJECTIVE_DICT, SVI, Trace_ELBO
     assert OBJECTIVE_DICT["graphelbo"](max_plate_nesting=1, vectorize_particles=True, num_particles=1).num_particles == 1
-    with pytest.raises(NotImplementedError):
-        OBJECTIVE_DICT["elbo"](num_particles=4)
+    assert OBJECTIVE_DICT["elbo"](num_particles=4).num_particles == 4
+    with pytest.raises(ValueError):
+        OBJECTIVE_DICT["elbo"](num_particles=0)
     with pytest.raises(NotImplementedError):
         OBJECTIVE_DICT["renyielbo"](alpha=2.0)
     sc = poutine.scale(scale=0.25)

@@ -41,7 +41,7 @@ def test_kat2_initial_word_topic_matrix_is_uniform_and_perplexity_is_V():
     assert abs(ll1 - float(expect)) < 1e-6 * abs(float(expect))
 
 
-@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("kind", ["rbf", "matern52", "matern32", "exponential"])
 def test_kat3_kernel_at_coincident_points_is_the_variance(kind):
     Z = grid_inducing_points([(0, 1), (0, 1)], [3, 3], dtype=torch.float64)
     K = kernel_matrix(kind, Z, Z, torch.tensor(0.2, dtype=torch.float64), torch.tensor(7.0, dtype=torch.float64))
@@ -107,7 +107,7 @@ def test_validate_dirichlet_param_shapes():
         validate_dirichlet_param(-1.0, 3, 4)
 
 
-@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("kind", ["rbf", "matern52", "matern32", "exponential"])
 def test_hand_derived_backward_matches_autograd(kind):
     m, eps = make_oracle(kind=kind, W=12, H=5, V=20, K=4, n_points=(4, 3))
     loss, grads = m.loss_and_grads(eps)
@@ -117,7 +117,10 @@ def test_hand_derived_backward_matches_autograd(kind):
     assert abs(loss - l2) < 1e-6 * abs(loss)         # torch evaluates lgamma(int32 counts) in float32
     for k in grads:
         a, b = grads[k].numpy(), g2[k]
-        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(a).max()), k
+        # the oracle keeps pyro's expanded-form distance, the fused version the direct (x-z)^2 (quirk Q12): at coincident
+        # points sqrt(r2 + 1e-12) sees the ~1e-16 cancellation noise, which the non-smooth kernels pass on at ~1e-8 relative
+        tol = 1e-10 if kind in ("rbf", "matern52") else 1e-7
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), k
 
 
 def test_scale_uses_global_n_for_minibatches():
