@@ -110,6 +110,9 @@ int gdrf_red_layout(const gdrf_ctx* c, int64_t out[6]) {
   return 0;
 }
 
+// row blocks of the ubar partial kernel: ~1024 workgroups, multiples of its 256-row staging step
+static int64_t ubar_rows_per_block(int64_t n) { return std::max<int64_t>(256, round_up((n + 1023) / 1024, 256)); }
+
 // number of row splits of the TN kernels: fill the chip's resident-workgroup slots (256 CUs x 3) with as
 // little last-round idling as possible, keep >= 8 chunks per split, cap the slab memory
 static int tn_nsplit(const gdrf_ctx* c, int64_t n, int BR) {
@@ -181,7 +184,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   }
   c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
   AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
-  c->ubar_blocks_cap = (n_cap + 2047) / 2048;
+  c->ubar_blocks_cap = std::min<int64_t>(1025, (n_cap + 255) / 256);     // upper bound of ubar_blocks(n) over n <= n_cap
   AL(c->ubar_part, (size_t)c->ubar_blocks_cap * K * c->Mp * c->esz)
   c->erows_grid_cap = 1024;
   AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
@@ -474,9 +477,10 @@ template <typename T, typename TS> struct Impl {
         dim3 gr1((Mp + 255) / 256, Mp, 1);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, ss, (const T*)slab_gt, ns, 1, Mp, 0, redT + roff(c, 3)); }
       ScopedTimer tm(c, 12, ss);
-      const int64_t nb = (n + 2047) / 2048;
+      const int64_t rpb = ubar_rows_per_block(n), nb = (n + rpb - 1) / rpb;
+      if (nb > c->ubar_blocks_cap) return fail(-1, "gdrf_step_local", "ubar partial buffer too small");
       hipLaunchKernelGGL(ubar_part_kernel<T>, dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, ss, P(c->W), n, Mp, K, P(c->locbar),
-                         ldk, (int64_t)2048, P(c->ubar_part));
+                         ldk, rpb, P(c->ubar_part));
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, ss, P(c->ubar_part), nb, (int64_t)K * Mp,
                          redT + roff(c, 0));
     }
