@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--knm-iters", type=int, default=20)
     ap.add_argument("--seed", type=int, default=777)
+    ap.add_argument("--mfma-mode", default="f32", choices=["f32", "bf16x6"],
+                    help="arithmetic of the Wbar contraction: native f32 MFMA, or exact-split emulation on bf16 MFMA")
     return ap.parse_args()
 
 
@@ -153,6 +155,10 @@ def main():
     svi = SVI(model=scale(model.model), guide=scale(model.guide), optim=optimizer, loss=objective)
     svi.row_offset = lo
     eng = model._engine_for(xs.shape[0])
+    if args.mfma_mode == "bf16x6":
+        from gdrf_amd import _lib as _l
+        _l.check(eng.lib.gdrf_set_mfma_mode(eng.ctx, 1), "gdrf_set_mfma_mode")
+        eng.mfma_mode = "bf16x6"
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -217,7 +223,7 @@ def main():
                                    f"M={M} ({'x'.join(map(str, args.n_points))} grid inducing points), {args.kernel} kernel, "
                                    f"Adam lr=1e-3, Trace_ELBO, 1 particle, jitter={args.jitter}, observations sharded over ranks",
                        "N": N, "M": M, "K": K, "V": args.vocab, "D": D, "rows_per_rank": n_loc,
-                       "jitter_level": eng.last_jitter_level, "stores_T": eng.stores_t},
+                       "jitter_level": eng.last_jitter_level, "stores_T": eng.stores_t, "wbar_mfma_mode": eng.mfma_mode},
             "roofline": {"bound": "mfma", "kernel": f"gemm_nt<{dom}>" if not dom.startswith("tn") else f"gemm_tn<{dom}>",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "flops_per_launch": flops[dom], "avg_ms": ms[dom]},

@@ -19,6 +19,8 @@ SIGNATURES = {
     "gdrf_ctx_create": (_int, [C.POINTER(_vp), _int, _i64, _int, _int, _int, _int, _int, _int]),
     "gdrf_ctx_create_ex": (_int, [C.POINTER(_vp), _int, _i64, _int, _int, _int, _int, _int, _int, _int]),
     "gdrf_stores_t": (_int, [_vp]),
+    "gdrf_set_mfma_mode": (_int, [_vp, _int]),
+    "gdrf_get_mfma_mode": (_int, [_vp]),
     "gdrf_ctx_destroy": (None, [_vp]),
     "gdrf_param_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_red_layout": (_int, [_vp, C.POINTER(_i64)]),

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "gemm_nt.h"
 #include "gemm_tn.h"
+#include "gemm_bf16x6.h"
 #include "kernels_mm.h"
 #include "kernels_n.h"
 
@@ -53,6 +54,8 @@ struct gdrf_ctx {
   // N-side precision
   void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
+  void *Bh;                   // 3 bf16 pieces of B_k (f32 contexts; bf16x6 form of the Wbar contraction)
+  int bf16x6;                 // 1: Wbar contraction on the bf16 matrix path with exact-split emulation (gemm_bf16x6.h)
   void *Tst;                  // T_k = W S_k kept for the backward, or nullptr (dense W B_k form instead)
   int64_t t_bs, t_ts;         // its per-topic / per-row-tile strides in elements
   void *slab, *ubar_part, *phibar_part;
@@ -148,7 +151,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->ssz = dtype == GDRF_F32_PURE ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
-  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr;
+  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = nullptr; c->bf16x6 = 0;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
@@ -167,6 +170,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->Knm, (size_t)n_cap * c->Mp * c->ssz)
   AL(c->pK, mm) AL(c->pL, mm * 8)          // probe scratch: K_uu without jitter, 8 level copies
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
+  if (c->esz == 4) { AL(c->Bh, (size_t)3 * K * c->Mp * c->Mp * 2) }
   AL(c->phi, (size_t)K * V * c->esz)
   AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)((c->Mp + 63) / 64) * c->ldk * c->esz)
   AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
@@ -253,6 +257,13 @@ static int ws_lookup(gdrf_ctx* c, int which, void** ptr, int64_t* nelem, int* es
 }
 int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) { int e; return ws_lookup(c, which, ptr, nelem, &e); }
 int gdrf_stores_t(const gdrf_ctx* c) { return c->Tst != nullptr; }
+int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
+  if (mode != 0 && mode != 1) return fail(-1, "gdrf_set_mfma_mode", "mode");
+  if (mode == 1 && (c->esz != 4 || c->Tst)) return fail(-1, "gdrf_set_mfma_mode", "bf16x6 needs float arrays and the dense Wbar form");
+  c->bf16x6 = mode;
+  return 0;
+}
+int gdrf_get_mfma_mode(const gdrf_ctx* c) { return c->bf16x6; }
 int gdrf_ws_elem_size(gdrf_ctx* c, int which) { void* p; int64_t n; int e; return ws_lookup(c, which, &p, &n, &e) ? -1 : e; }
 
 int gdrf_set_timing(gdrf_ctx* c, int enable) {
@@ -368,6 +379,25 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
+  // Wbar on the bf16 matrix path (f32 contexts only)
+  static int wbar_bf16x6(gdrf_ctx* c, int64_t n, const T* U, int64_t rtiles, hipStream_t s) {
+    if constexpr (std::is_same<T, float>::value) {
+      const int Mp = c->Mp, K = c->K;
+      const int64_t nb = (int64_t)K * Mp * Mp;
+      hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, (__bf16*)c->Bh);
+      BwdWbarBf16Args a{(const float*)c->W, n, c->M, Mp, K, (const __bf16*)c->Bh, nb, (const float*)c->vbar, (const float*)c->locbar,
+                        c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar};
+      const size_t lds = Bf16x6Cfg::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(float);
+      HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int nct_ = (Mp + GDRF_TILE - 1) / GDRF_TILE;
+      hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel, dim3((unsigned)round_up(rtiles * nct_, 8)), dim3(256), lds, s, a);
+      LAUNCHCHK("wbar_bf16x6");
+      return 0;
+    } else {
+      return fail(-1, "wbar_bf16x6", "float arrays only");
+    }
+  }
+
   // K_nm in the solve precision with the exact exponential, zero-padded to Mp columns
   static int knm_solve(gdrf_ctx* c, const T* X, int64_t n, hipStream_t s) {
     ScopedTimer tm(c, 1, s);
@@ -453,6 +483,8 @@ template <typename T, typename TS> struct Impl {
         if (lds > 48 * 1024)
           HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarTProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarTProb<T>>), grid, dim3(256), lds, s, p);
+      } else if (c->bf16x6) {
+        if ((rc = wbar_bf16x6(c, n, U, rtiles, s))) return rc;
       } else {
         BwdWbarProb<T> p{{}, {}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
         if (lds > 48 * 1024)

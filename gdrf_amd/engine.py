@@ -33,7 +33,7 @@ class Engine:
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
                  device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
-                 store_t="auto"):
+                 store_t="auto", mfma_mode: str = "f32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -57,6 +57,11 @@ class Engine:
         self.pure_fp32 = bool(pure_fp32) and dtype == torch.float32
         self.ctx = ctx
         self.stores_t = bool(self.lib.gdrf_stores_t(self.ctx))
+        self.mfma_mode = mfma_mode
+        if mfma_mode not in ("f32", "bf16x6"):
+            raise ValueError("mfma_mode must be 'f32' or 'bf16x6'")
+        if mfma_mode == "bf16x6":
+            _lib.check(self.lib.gdrf_set_mfma_mode(self.ctx, 1), "gdrf_set_mfma_mode")
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
         self.layout = dict(log_lengthscale=lay[0], log_variance=lay[1], log_noise=lay[2], u_loc=lay[3], phi_unc=lay[4],

@@ -25,12 +25,12 @@ def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.f
     return m, eps
 
 
-def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=False, store_t="auto"):
+def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=False, store_t="auto", mfma_mode="f32"):
     """gdrf_amd.Engine holding exactly the oracle's parameters / inducing points / Dirichlet prior."""
     from gdrf_amd.engine import Engine
     dtype = m.dtype if dtype is None else dtype
     eng = Engine(n_cap or m.N, m.M, m.K, m.V, m.D, dtype=dtype, kernel=m.kind, device=device, jitter=m.jitter,
-                 maxjitter=m.maxjitter, process_group=None, pure_fp32=pure_fp32, store_t=store_t)
+                 maxjitter=m.maxjitter, process_group=None, pure_fp32=pure_fp32, store_t=store_t, mfma_mode=mfma_mode)
     eng.set_inducing_points(m.Z)
     eng.set_dirichlet(m.alpha)
     load_params(eng, m)
