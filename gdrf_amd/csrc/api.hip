@@ -54,7 +54,7 @@ struct gdrf_ctx {
   // N-side precision
   void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
-  void *Bh;                   // 3 bf16 pieces of B_k (f32 contexts; bf16x6 form of the Wbar contraction)
+  void *Bh, *STh, *Wh;        // 3 bf16 pieces each of B_k, S_k^T and W (f32 contexts; exact-split bf16 MFMA forms)
   int bf16x6;                 // 1: Wbar contraction on the bf16 matrix path with exact-split emulation (gemm_bf16x6.h)
   void *Tst;                  // T_k = W S_k kept for the backward, or nullptr (dense W B_k form instead)
   int64_t t_bs, t_ts;         // its per-topic / per-row-tile strides in elements
@@ -118,9 +118,9 @@ static int64_t ubar_rows_per_block(int64_t n) { return std::max<int64_t>(256, ro
 
 // number of row splits of the TN kernels: fill the chip's resident-workgroup slots (256 CUs x 3) with as
 // little last-round idling as possible, keep >= 8 chunks per split, cap the slab memory
-static int tn_nsplit(const gdrf_ctx* c, int64_t n, int BR) {
+static int tn_nsplit(const gdrf_ctx* c, int64_t n, int BR, int wg_per_cu = 3) {
   const int tiles = c->K * c->nt * (c->nt + 1) / 2;
-  const double slots = 256.0 * 3.0;
+  const double slots = 256.0 * wg_per_cu;
   int64_t maxs = (n + 8 * BR - 1) / (8 * BR);
   if (maxs > 64) maxs = 64;
   if (maxs < 1) maxs = 1;
@@ -151,7 +151,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->ssz = dtype == GDRF_F32_PURE ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
-  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = nullptr; c->bf16x6 = 0;
+  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->bf16x6 = 0;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
@@ -170,7 +170,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->Knm, (size_t)n_cap * c->Mp * c->ssz)
   AL(c->pK, mm) AL(c->pL, mm * 8)          // probe scratch: K_uu without jitter, 8 level copies
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
-  if (c->esz == 4) { AL(c->Bh, (size_t)3 * K * c->Mp * c->Mp * 2) }
+  if (c->esz == 4) { AL(c->Bh, (size_t)3 * K * c->Mp * c->Mp * 2) AL(c->STh, (size_t)3 * K * c->Mp * c->Mp * 2) }
   AL(c->phi, (size_t)K * V * c->esz)
   AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)((c->Mp + 63) / 64) * c->ldk * c->esz)
   AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
@@ -187,6 +187,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
     if (store_t == GDRF_STORE_T_ON) { AL(c->Tst, tbytes) }
   }
   c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
+  if (c->esz == 4) c->nsplit_cap = std::max(c->nsplit_cap, tn_nsplit(c, n_cap, 32, 2));     // the bf16x6 TN form runs 2 workgroups per CU
   AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
   c->ubar_blocks_cap = std::min<int64_t>(1025, (n_cap + 255) / 256);     // upper bound of ubar_blocks(n) over n <= n_cap
   AL(c->ubar_part, (size_t)c->ubar_blocks_cap * K * c->Mp * c->esz)
@@ -260,6 +261,13 @@ int gdrf_stores_t(const gdrf_ctx* c) { return c->Tst != nullptr; }
 int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
   if (mode != 0 && mode != 1) return fail(-1, "gdrf_set_mfma_mode", "mode");
   if (mode == 1 && (c->esz != 4 || c->Tst)) return fail(-1, "gdrf_set_mfma_mode", "bf16x6 needs float arrays and the dense Wbar form");
+  HIPCHK(hipSetDevice(c->dev));
+  if (mode == 1 && !c->Wh) {          // bf16 pieces of W: 3 x n_cap x Mp halfwords, allocated on first use
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)3 * c->ncap * c->Mp * 2);
+    if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(Wh)", hipGetErrorString(e));
+    c->Wh = p; c->allocs.push_back(p);
+  }
   c->bf16x6 = mode;
   return 0;
 }
@@ -379,17 +387,58 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
+  // bf16 pieces of W and of S_k^T, then tt on the bf16 matrix path (f32 contexts only)
+  static int fwd_t_bf16x6(gdrf_ctx* c, int64_t n, int64_t rtiles, hipStream_t s) {
+    if constexpr (std::is_same<T, float>::value) {
+      const int Mp = c->Mp, K = c->K;
+      const int64_t nb = (int64_t)K * Mp * Mp, nw = n * Mp;
+      {
+        ScopedTimer tm(c, 2, s);
+        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->ST, nb, (__bf16*)c->STh, nb);
+        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nw / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->W, nw, (__bf16*)c->Wh,
+                           (int64_t)c->ncap * Mp);
+      }
+      ScopedTimer tm(c, 5, s);
+      // topics per group: as many lower-triangular S^T piece panels (3 x ~0.6 Mp^2 halfwords each) as fit in 2 MB
+      const double panel = 0.625 * 6.0 * (double)Mp * Mp;
+      const int KG = std::max(1, std::min(K, (int)(2.0 * 1024 * 1024 / panel)));
+      FwdTBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, (int)((rtiles + 7) / 8),
+                     (const __bf16*)c->STh, nb, (float*)c->tt, c->ldk};
+      HIPCHK(hipFuncSetAttribute((const void*)fwd_t_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Bf16x6Cfg::LDS_BYTES));
+      hipLaunchKernelGGL(fwd_t_bf16x6_kernel, dim3((unsigned)(8 * K * ((rtiles + 7) / 8))), dim3(256), Bf16x6Cfg::LDS_BYTES, s, a);
+      LAUNCHCHK("fwd_t_bf16x6");
+      return 0;
+    } else {
+      return fail(-1, "fwd_t_bf16x6", "float arrays only");
+    }
+  }
+
+  // C = Wh^T diag(scale) B over the observations on the bf16 matrix path (f32 contexts only); A side = the pieces of W
+  static int tn_bf16x6(gdrf_ctx* c, const float* B, const float* scale, int64_t scale_bs, int64_t n, int64_t rps, int sym, float* slab,
+                       int nbatch, int ns, int ntiles, hipStream_t s) {
+    if constexpr (std::is_same<T, float>::value) {
+      TNBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns};
+      constexpr int lds = 2 * 3 * 32 * 128 * 2;
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(gemm_tn_bf16x6_kernel, dim3((unsigned)(ntiles * nbatch * ns)), dim3(256), lds, s, a);
+      return 0;
+    } else {
+      return fail(-1, "tn_bf16x6", "float arrays only");
+    }
+  }
+
   // Wbar on the bf16 matrix path (f32 contexts only)
   static int wbar_bf16x6(gdrf_ctx* c, int64_t n, const T* U, int64_t rtiles, hipStream_t s) {
     if constexpr (std::is_same<T, float>::value) {
       const int Mp = c->Mp, K = c->K;
       const int64_t nb = (int64_t)K * Mp * Mp;
-      hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, (__bf16*)c->Bh);
-      BwdWbarBf16Args a{(const float*)c->W, n, c->M, Mp, K, (const __bf16*)c->Bh, nb, (const float*)c->vbar, (const float*)c->locbar,
-                        c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar};
+      hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, (__bf16*)c->Bh, nb);
+      BwdWbarBf16Args a{(const float*)c->W, (const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, c->M, Mp, K, (const __bf16*)c->Bh, nb,
+                        (const float*)c->vbar, (const float*)c->locbar, c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar};
       const size_t lds = Bf16x6Cfg::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(float);
-      HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (lds > 160 * 1024) return fail(-1, "wbar_bf16x6", "too many topics for the LDS scale table");
       const int nct_ = (Mp + GDRF_TILE - 1) / GDRF_TILE;
+      HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel, dim3((unsigned)round_up(rtiles * nct_, 8)), dim3(256), lds, s, a);
       LAUNCHCHK("wbar_bf16x6");
       return 0;
@@ -446,7 +495,9 @@ template <typename T, typename TS> struct Impl {
     }
     HIPCHK(hipEventRecord(c->ev_loc, c->side));
     // (2) tt_kn = ||S_k^T w_n||^2
-    {
+    if (c->bf16x6) {
+      if ((rc = fwd_t_bf16x6(c, n, rtiles, s))) return rc;
+    } else {
       ScopedTimer tm(c, 5, s);
       FwdTProb<T> p{{K}, {}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
       hipLaunchKernelGGL((gemm_nt_kernel<T, FwdTProb<T>>), dim3((unsigned)(8 * K * ((rtiles + 7) / 8))), dim3(256), C::LDS_BYTES, s, p);
@@ -499,12 +550,16 @@ template <typename T, typename TS> struct Impl {
     {
       hipStream_t ss = c->side;
       const int BR = TNCfg<T>::BR;
-      const int ns = std::min(tn_nsplit(c, n, BR), c->nsplit_cap);
+      const int ns = std::min(tn_nsplit(c, n, BR, c->bf16x6 ? 2 : 3), c->nsplit_cap);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
       T* slab_gt = P(c->slab) + (int64_t)c->nsplit_cap * K * mm;           // the (K+1)-th batch region of the slab buffer
       TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, slab_gt, 1, ns};
       { ScopedTimer tm(c, 10, ss);
-        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, ss, b); }
+        if (c->bf16x6) {
+          if ((rc = tn_bf16x6(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ss))) return rc;
+        } else {
+          hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, ss, b);
+        } }
       { ScopedTimer tm(c, 11, ss);
         dim3 gr1((Mp + 255) / 256, Mp, 1);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, ss, (const T*)slab_gt, ns, 1, Mp, 0, redT + roff(c, 3)); }
@@ -531,11 +586,15 @@ template <typename T, typename TS> struct Impl {
     // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
     {
       const int BR = TNCfg<T>::BR;
-      const int ns = std::min(tn_nsplit(c, n, BR), c->nsplit_cap);
+      const int ns = std::min(tn_nsplit(c, n, BR, c->bf16x6 ? 2 : 3), c->nsplit_cap);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
       TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K, ns};
       { ScopedTimer tm(c, 9, s);
-        hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * (c->nt + 1) / 2 * K * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, a); }
+        if (c->bf16x6) {
+          if ((rc = tn_bf16x6(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, c->nt * (c->nt + 1) / 2, s))) return rc;
+        } else {
+          hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * (c->nt + 1) / 2 * K * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, a);
+        } }
       { ScopedTimer tm(c, 11, s);
         dim3 gr((Mp + 255) / 256, Mp, K);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2)); }

@@ -33,7 +33,7 @@ class Engine:
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
                  device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
-                 store_t="auto", mfma_mode: str = "f32"):
+                 store_t="auto", mfma_mode: str = "auto"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -57,9 +57,13 @@ class Engine:
         self.pure_fp32 = bool(pure_fp32) and dtype == torch.float32
         self.ctx = ctx
         self.stores_t = bool(self.lib.gdrf_stores_t(self.ctx))
+        # arithmetic of the f32 GEMM-shaped contractions: "bf16x6" = exact-split emulation on the bf16 matrix path (f32-level
+        # error, csrc/gemm_bf16x6.h), "f32" = native f32 MFMA; "auto" = bf16x6 wherever it applies (float32 arrays, dense Wbar)
+        if mfma_mode not in ("auto", "f32", "bf16x6"):
+            raise ValueError("mfma_mode must be 'auto', 'f32' or 'bf16x6'")
+        if mfma_mode == "auto":
+            mfma_mode = "bf16x6" if (dtype == torch.float32 and not self.stores_t) else "f32"
         self.mfma_mode = mfma_mode
-        if mfma_mode not in ("f32", "bf16x6"):
-            raise ValueError("mfma_mode must be 'f32' or 'bf16x6'")
         if mfma_mode == "bf16x6":
             _lib.check(self.lib.gdrf_set_mfma_mode(self.ctx, 1), "gdrf_set_mfma_mode")
         lay = (C.c_int64 * 7)()

@@ -89,6 +89,7 @@ class SparseMultinomialGDRF:
         randomize_iters: int = 100,
         dtype: torch.dtype = torch.float32,
         pure_fp32: bool = False,
+        mfma_mode: str = "auto",
         inducing_points: Optional[torch.Tensor] = None,
         seed: Optional[int] = None,
         **kwargs,
@@ -112,6 +113,7 @@ class SparseMultinomialGDRF:
         self.device = torch.device(device)
         self.dtype = dtype
         self._pure_fp32 = bool(pure_fp32)
+        self._mfma_mode = mfma_mode          # Engine(mfma_mode=...): "auto" | "f32" | "bf16x6"
         self._kernel = kernel
         if kernel.input_dim != self._n_dims:
             raise ValueError("kernel.input_dim does not match the world's dimensionality")
@@ -157,7 +159,7 @@ class SparseMultinomialGDRF:
         if e is not None and n <= e.n_cap:
             return e
         new = Engine(n, self.M, self._K, self._V, self.D, dtype=self.dtype, kernel=self._kernel.name, device=self.device,
-                     jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32)
+                     jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32, mfma_mode=self._mfma_mode)
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
         if e is None:

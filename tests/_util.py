@@ -25,7 +25,7 @@ def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.f
     return m, eps
 
 
-def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=False, store_t="auto", mfma_mode="f32"):
+def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=False, store_t="auto", mfma_mode="auto"):
     """gdrf_amd.Engine holding exactly the oracle's parameters / inducing points / Dirichlet prior."""
     from gdrf_amd.engine import Engine
     dtype = m.dtype if dtype is None else dtype

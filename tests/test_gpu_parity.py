@@ -231,7 +231,7 @@ def test_bf16x6_against_fp64_product_of_the_same_inputs():
     asum, S, u_loc), so the only difference left is how the kernel multiplies.  The split-bf16 form must be as close to that
     fp64 product as the native f32 MFMA form is (both ~1e-7), and the two must agree with each other to f32 rounding."""
     m, eps = make_oracle(dtype=torch.float32, jitter=1e-4, kind="rbf", W=40, H=25, V=20, K=6, n_points=(12, 12), lengthscale=0.08)
-    out = {}
+    out, tt_err, tn_err = {}, {}, {}
     for mode in ("f32", "bf16x6"):
         eng = engine_from_oracle(m, mfma_mode=mode, store_t=False)
         xs, ws, e = dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng)
@@ -247,9 +247,36 @@ def test_bf16x6_against_fp64_product_of_the_same_inputs():
         for k in range(m.K):
             ref += (2 * vbar[k])[:, None] * (Wm @ (S[k] @ S[k].T))
         out[mode] = (eng.workspace("Wbar", n).cpu().double().numpy(), ref)
+        tt_ref = np.stack([((Wm @ S[k]) ** 2).sum(1) for k in range(m.K)])
+        tt_err[mode] = relerr(eng.workspace("tt", n).cpu().double().numpy(), tt_ref)
+        # the reductions over the observations: A_k = W^T diag(vbar_k) W (lower triangle) and GT = W^T Wbar
+        Mp, lay = (m.M + 31) // 32 * 32, eng.red_layout
+        A = eng.red_T[lay["A"]:lay["A"] + m.K * Mp * Mp].view(m.K, Mp, Mp)[:, :m.M, :m.M].cpu().double().numpy()
+        GT = eng.red_T[lay["GT"]:lay["GT"] + Mp * Mp].view(Mp, Mp)[:m.M, :m.M].cpu().double().numpy()
+        A_ref = np.stack([Wm.T @ (vbar[k][:, None] * Wm) for k in range(m.K)])
+        tn_err[mode] = dict(A=relerr(np.tril(A), np.tril(A_ref)), GT=relerr(GT, Wm.T @ out[mode][0]))
     e_f32 = relerr(*out["f32"])
     e_b = relerr(*out["bf16x6"])
     cross = relerr(out["bf16x6"][0], out["f32"][0])
     print("Wbar vs fp64 product of the same inputs: f32 MFMA %.2e, bf16x6 %.2e; bf16x6 vs f32 %.2e" % (e_f32, e_b, cross))
     # measured on MI355X: f32 MFMA 3.1e-6, bf16x6 2.2e-6 (relative to max|Wbar|; the sum cancels large terms), cross 3.2e-6
-    assert e_f32 < 2e-5 and e_b < 1.5 * e_f32 + 1e-7 and cross < 3 * e_f32 + 1e-7
+    print("tt = |S_k^T w|^2 vs fp64 product of the same inputs:", tt_err)
+    assert tt_err["f32"] < 2e-6 and tt_err["bf16x6"] < 1.5 * tt_err["f32"] + 1e-7
+    print("A_k, GT vs fp64 products of the same inputs:", tn_err)
+    for q in ("A", "GT"):
+        assert tn_err["f32"][q] < 2e-5 and tn_err["bf16x6"][q] < 1.5 * tn_err["f32"][q] + 1e-7, tn_err
+    assert e_f32 < 2e-5 and e_b < 1.5 * e_f32 + 1e-7
+
+
+def test_bf16x6_is_deterministic():
+    """Two engines, two calls each: tt and Wbar of the split-bf16 kernels are bit-identical (fixed accumulation order, no atomics)."""
+    m, eps = make_oracle(dtype=torch.float32, jitter=1e-4, kind="rbf", W=40, H=25, V=20, K=6, n_points=(12, 12), lengthscale=0.08)
+    got = []
+    for _ in range(2):
+        eng = engine_from_oracle(m, mfma_mode="bf16x6", store_t=False)
+        xs, ws, e = dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng)
+        for _ in range(2):
+            eng.loss_and_grads(xs, ws, e)
+            got.append((eng.workspace("tt", m.N).cpu(), eng.workspace("Wbar", m.N).cpu()))
+    for tt, wb in got[1:]:
+        assert torch.equal(tt, got[0][0]) and torch.equal(wb, got[0][1])
