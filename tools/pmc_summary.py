@@ -35,11 +35,12 @@ def main():
                     seen.add(key)
                     dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
     counters = sorted({c for k in val for c in val[k]})
-    print(",".join(["kernel", "dispatches", "mean_ms"] + counters))
+    out = csv.writer(sys.stdout)
+    out.writerow(["kernel", "dispatches", "mean_ms"] + counters)
     for k in sorted(val, key=lambda k: -sum(dur[k])):
         n = max(len(v) for v in val[k].values())
         ms = sum(dur[k]) / max(1, len(dur[k]))
-        print(",".join([k, str(n), "%.4f" % ms] + ["%.6g" % (sum(val[k][c]) / len(val[k][c])) if val[k][c] else "" for c in counters]))
+        out.writerow([k, str(n), "%.4f" % ms] + ["%.6g" % (sum(val[k][c]) / len(val[k][c])) if val[k][c] else "" for c in counters])
 
 
 if __name__ == "__main__":
