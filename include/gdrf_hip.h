@@ -44,9 +44,11 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
 enum { GDRF_STORE_T_OFF = 0, GDRF_STORE_T_ON = 1, GDRF_STORE_T_AUTO = 2 };
 int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id, int store_t);
 int gdrf_stores_t(const gdrf_ctx* ctx);
-/* Arithmetic of the dominant contraction Wbar = sum_k diag(2 vbar_k) W B_k in float contexts: 0 = v_mfma_f32_16x16x4_f32
- * (native f32 MFMA), 1 = exact-split emulation on v_mfma_f32_16x16x32_bf16 (each f32 operand as 3 bf16 pieces, the 6 cross
- * products of weight >= 2^-16, f32 accumulation: f32-level error at 16/6 of the f32 MFMA rate; gemm_bf16x6.h). */
+/* Arithmetic of the four f32 GEMM-shaped contractions of the step (tt = |S_k^T w|^2, Wbar, A_k = W^T diag(vbar_k) W,
+ * G^T = W^T Wbar) in float contexts: 0 = v_mfma_f32_16x16x4_f32 (native f32 MFMA), 1 = exact-split emulation on
+ * v_mfma_f32_16x16x32_bf16 (each f32 operand as 3 bf16 pieces, the 6 cross products of weight >= 2^-16, f32
+ * accumulation: f32-level error at 16/6 of the f32 MFMA rate; gemm_bf16x6.h).  Mode 1 needs float arrays and the dense
+ * Wbar form (GDRF_STORE_T_OFF); a fresh context is in mode 0, gdrf_amd.Engine selects 1 for float32 by default. */
 int gdrf_set_mfma_mode(gdrf_ctx* ctx, int mode);
 int gdrf_get_mfma_mode(const gdrf_ctx* ctx);
 void gdrf_ctx_destroy(gdrf_ctx* ctx);
