@@ -62,7 +62,7 @@ struct gdrf_ctx {
   double *dpart, *dsmall;     // dsmall: [0..1] kuu sums, [8] ll_const scratch
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
   double* alpha_dev; double lgam_const;
-  Hyper* hyp; int* flag;
+  Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[8..16): probe levels failed
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
   hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join;
   std::vector<void*> allocs;
@@ -198,7 +198,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
-  AL(c->hyp, sizeof(Hyper)) AL(c->flag, 64)
+  AL(c->hyp, sizeof(Hyper)) AL(c->hyp_probe, sizeof(Hyper)) AL(c->flag, 64)
 #undef AL
   HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -327,21 +327,22 @@ template <typename T, typename TS> struct Impl {
   }
 
   // nlev (<= 8) Cholesky attempts in ONE launch, in the N-side precision (what the reference's fp32
-  // torch.linalg.cholesky would see): K_uu built once, one workgroup per cumulative jitter; flags in c->flag[0..nlev)
+  // torch.linalg.cholesky would see): K_uu built once, one workgroup per cumulative jitter; flags in c->flag[8..8+nlev)
+  // (slot 0 is the solve factorisation's, so a probe may run on another stream beside gdrf_factorize)
   static int probe(gdrf_ctx* c, const T* Z, const T* params, const double* jitters, int nlev, hipStream_t s) {
     const int Mp = c->Mp, M = c->M;
     ScopedTimer tm(c, 0, s);
-    HIPCHK(hipMemsetAsync(c->flag, 0, 64, s));
-    hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
+    HIPCHK(hipMemsetAsync(c->flag + 8, 0, 32, s));
+    hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp_probe);
     dim3 g2((Mp + 255) / 256, Mp);
-    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp, 0.0, P(c->pK));
+    hipLaunchKernelGGL(kuu_kernel<T>, g2, dim3(256), 0, s, Z, M, Mp, c->D, c->kind, c->hyp_probe, 0.0, P(c->pK));
     JitterLevels jl;
     for (int l = 0; l < 8; ++l) jl.v[l] = l < nlev ? jitters[l] : 0.0;
     dim3 g3((Mp + 255) / 256, Mp, nlev);
     hipLaunchKernelGGL(level_copies_kernel<T>, g3, dim3(256), 0, s, (const T*)P(c->pK), M, Mp, jl, P(c->pL));
     if (chol_lds_bytes<T>(M) > 48 * 1024)
       HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<T>(M)));
-    hipLaunchKernelGGL(chol_kernel<T>, dim3(nlev), dim3(1024), chol_lds_bytes<T>(M), s, P(c->pL), M, Mp, c->flag, (int64_t)Mp * Mp);
+    hipLaunchKernelGGL(chol_kernel<T>, dim3(nlev), dim3(1024), chol_lds_bytes<T>(M), s, P(c->pL), M, Mp, c->flag + 8, (int64_t)Mp * Mp);
     LAUNCHCHK("probe");
     return 0;
   }
@@ -354,7 +355,7 @@ template <typename T, typename TS> struct Impl {
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     const int64_t nz = (int64_t)M * c->D;
     hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, nz, Z, Q(c->Zs));
-    HIPCHK(hipMemsetAsync(c->flag, 0, 64, s));
+    HIPCHK(hipMemsetAsync(c->flag, 0, 32, s));
     hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
     HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, s));
     if (chol_lds_bytes<TS>(M) > 48 * 1024)
@@ -707,9 +708,8 @@ int gdrf_probe(gdrf_ctx* c, const void* Z, const void* params, const double* jit
   hipStream_t s = (hipStream_t)stream;
   int rc = probe_dispatch(c, Z, params, jitters, nlev, s);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(failed_host, c->flag, sizeof(int) * nlev, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(failed_host, c->flag + 8, sizeof(int) * nlev, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipMemsetAsync(c->flag, 0, 64, s));
   return 0;
 }
 

@@ -768,6 +768,7 @@ __global__ void grad_small_kernel(int M, int Mp, int K, int V, const Hyper* __re
   lp = block_sum(lp, scratch);
   if (threadIdx.x == 0) {
     const double lp_phi = lp + lgam_const;
+    if (ll_const != ll_const) ll_const = red_d[6];          // NaN: the (all-reduced) data constant travels in the payload
     const double elbo_n = red_d[0] + red_d[1] + ll_const + lp_phi;
     out_d[0] = -elbo_n / n_global;            // loss
     out_d[1] = (double)(*flag);

@@ -85,6 +85,9 @@ class Engine:
         self.opt_step = 0
         self.last_jitter_level = 0
         self._ll_cache = None
+        self._guess_level: Optional[int] = None      # jitter level of the previous step: this step starts on it speculatively
+        self._probe_stream = torch.cuda.Stream(device=self.device)
+        self.speculate = True
 
     def __del__(self):
         try:
@@ -244,7 +247,54 @@ class Engine:
         if tuple(eps.shape[1:]) != (self.K, n) or eps.dtype != self.dtype or not eps.is_contiguous() or eps.device != self.device:
             raise ValueError(f"eps must be a contiguous ([P,]{self.K},{n}) {self.dtype} tensor on {self.device}")
         s = _stream_ptr(self.device)
-        self.factorize(force_level)
+        llc = self.ll_const(ws) if ll_const is None else ll_const
+        ng = float(n if n_global is None else n_global)
+        guess = self._guess_level if (force_level is None and self.speculate) else None
+        if guess is None:
+            self.factorize(force_level)
+            self._local_and_finish(xs, ws, eps, P, n, ng, llc, s)
+        else:
+            # Speculate on the previous step's jitter level: the solve-precision factorisation and the whole step go onto
+            # the main stream at once, the array-precision probe (which decides the level, as the reference's fp32
+            # jittercholesky would) runs beside them on a second stream, and the host only waits for the probe and for the
+            # factorisation flag while the GPU is busy with the N-side kernels.  A wrong guess (the level moved, or the
+            # f64 factorisation failed where the f32 one passed) redoes the step on the right level; every rank holds the
+            # same parameters, so every rank takes the same branch.
+            main = torch.cuda.current_stream(self.device)
+            self._probe_stream.wait_stream(main)
+            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(guess), s),
+                       "gdrf_factorize")
+            fact_done = torch.cuda.Event()
+            fact_done.record(main)
+            self._local_and_finish(xs, ws, eps, P, n, ng, llc, s)
+            ps = self._probe_stream.cuda_stream
+            level = self._probe_level(ps)
+            failed = C.c_int()
+            self._probe_stream.wait_event(fact_done)
+            _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), ps), "gdrf_chol_failed")
+            if level == guess and not failed.value:
+                self.last_jitter_level = level
+            else:
+                torch.cuda.synchronize(self.device)
+                self.factorize(None)
+                self._local_and_finish(xs, ws, eps, P, n, ng, llc, s)
+        self._guess_level = self.last_jitter_level if force_level is None else None
+
+    def _probe_level(self, stream_ptr: int) -> int:
+        """First cumulative-jitter level whose array-precision Cholesky succeeds (probe only; raises past maxjitter)."""
+        level = 0
+        while level < self.maxjitter:
+            nlev = min(4 if level == 0 else 8, self.maxjitter - level)
+            jit = (C.c_double * nlev)(*[self.jitter_total(level + l) for l in range(nlev)])
+            flags = (C.c_int * nlev)()
+            _lib.check(self.lib.gdrf_probe(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jit, nlev, flags, stream_ptr), "gdrf_probe")
+            ok = [l for l in range(nlev) if not flags[l]]
+            if ok:
+                return level + ok[0]
+            level += nlev
+        raise RuntimeError("reached max jitter, covariance is unstable")
+
+    def _local_and_finish(self, xs, ws, eps, P, n, ng, llc, s):
         for p in range(P):
             _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n, self.Z.data_ptr(),
                                                 self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
@@ -258,8 +308,6 @@ class Engine:
         if P > 1:
             self.red_T.copy_(acc_T / P)
             self.red_d.copy_(acc_d / P)
-        llc = self.ll_const(ws) if ll_const is None else ll_const
-        ng = float(n if n_global is None else n_global)
         if self._distributed():
             import torch.distributed as dist
             pg = None if isinstance(self.pg, str) else self.pg
@@ -280,8 +328,8 @@ class Engine:
 
     def _finish(self, n_global: float, ll_const: Optional[float]):
         s = _stream_ptr(self.device)
-        if ll_const is None:                         # reduced copy travels in red_d[6]
-            ll_const = float(self.red_d[6].item())
+        if ll_const is None:                         # the reduced copy travels in red_d[6]; the kernel reads it there (no host sync)
+            ll_const = float("nan")
         _lib.check(self.lib.gdrf_step_finish(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.red_T.data_ptr(),
                                              self.red_d.data_ptr(), n_global, ll_const, self.grads.data_ptr(),
                                              self.out_d.data_ptr(), s), "gdrf_step_finish")

@@ -80,7 +80,8 @@ int gdrf_ll_const(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* out_h
  * jitters_host[0..nlev) factorised concurrently in ONE launch, in the array precision -- the precision in
  * which the reference's torch.linalg.cholesky decides whether more jitter is needed.  failed_host[l] != 0 when
  * attempt l hit a non-positive pivot; the caller takes the first success (same outcome as trying them in order).
- * Synchronises the stream. */
+ * Synchronises the stream.  Uses its own workspace and flag slots: it may run on a second stream beside
+ * gdrf_factorize()/gdrf_step_local() of the same parameters (gdrf_amd.Engine overlaps it that way). */
 int gdrf_probe(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const double* jitters_host, int nlev,
                int* failed_host, void* stream);
 
@@ -97,7 +98,8 @@ int gdrf_step_local(gdrf_ctx* ctx, const void* X_dev, const int32_t* ws_dev, con
 
 /* Replicated epilogue: Cholesky / kernel hyper-parameter backward, constraint Jacobians, Dirichlet
  * term, loss.  grads (same layout as params) = d loss / d unconstrained.  out_d (8 doubles) =
- * {loss, cholesky_failed, site_sum, loglik_sum, log_prior_phi, ...}. */
+ * {loss, cholesky_failed, site_sum, loglik_sum, log_prior_phi, ...}.  ll_const = the data-only constant of the
+ * Multinomial log-likelihood (gdrf_ll_const, summed over ranks); pass NaN to take it from red_d[6] on the device. */
 int gdrf_step_finish(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const void* red_T_dev,
                      const double* red_d_dev, double n_global, double ll_const, void* grads_dev, double* out_d_dev,
                      void* stream);

@@ -280,3 +280,28 @@ def test_bf16x6_is_deterministic():
             got.append((eng.workspace("tt", m.N).cpu(), eng.workspace("Wbar", m.N).cpu()))
     for tt, wb in got[1:]:
         assert torch.equal(tt, got[0][0]) and torch.equal(wb, got[0][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_speculative_jitter_level_gives_identical_steps(dtype):
+    """Engine.loss_and_grads starts on the previous step's jitter level while the probe runs on a second stream; the
+    parameters after several Adam steps must be bit-identical to the synchronous probe-then-factorise order, also when the
+    guess is wrong (forced here) and the step is redone."""
+    m, eps = make_oracle(dtype=dtype, jitter=1e-6, kind="rbf", W=30, H=20, V=12, K=4, n_points=(8, 6), lengthscale=0.15)
+    runs = {}
+    for mode in ("sync", "speculate", "wrong_guess"):
+        eng = engine_from_oracle(m)
+        eng.speculate = mode != "sync"
+        xs, ws, e = dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng)
+        losses, levels = [], []
+        for t in range(4):
+            if mode == "wrong_guess" and t >= 1:
+                eng._guess_level = eng.last_jitter_level + 1
+            eng.loss_and_grads(xs, ws, e)
+            eng.adam("adam", 1e-2)
+            losses.append(eng.read_out()["loss"])
+            levels.append(eng.last_jitter_level)
+        runs[mode] = (eng.params.clone().cpu(), losses, levels)
+    for mode in ("speculate", "wrong_guess"):
+        assert torch.equal(runs[mode][0], runs["sync"][0]), mode
+        assert runs[mode][1] == runs["sync"][1] and runs[mode][2] == runs["sync"][2], mode
