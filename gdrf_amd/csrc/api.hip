@@ -64,7 +64,8 @@ struct gdrf_ctx {
   double* alpha_dev; double lgam_const;
   Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[8..16): probe levels failed
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
-  hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join;
+  hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join, ev_fact0, ev_fact;
+  int fact_pending;           // a factorisation has been queued on the side stream: consumers wait for ev_fact
   std::vector<void*> allocs;
   // optional per-kernel HIP-event timing (gdrf_set_timing): events recorded on the launch stream
   int timing;
@@ -152,7 +153,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->bf16x6 = 0;
-  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = nullptr;
+  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -201,7 +202,8 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->hyp, sizeof(Hyper)) AL(c->hyp_probe, sizeof(Hyper)) AL(c->flag, 64)
 #undef AL
   HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact})
+    HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(hipMemset(c->flag, 0, 64));
   HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
   std::vector<double> a((size_t)K * V, 1.0);
@@ -215,7 +217,7 @@ void gdrf_ctx_destroy(gdrf_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& t : c->tev) { (void)hipEventDestroy(t.second.first); (void)hipEventDestroy(t.second.second); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join, c->ev_fact0, c->ev_fact}) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
@@ -293,12 +295,19 @@ int gdrf_get_timing(gdrf_ctx* c, double* ms_out, int64_t* cnt_out, int nslots) {
   return 0;
 }
 
+// make stream s wait for the factorisation queued on the side stream (no-op before the first gdrf_factorize)
+static int join_fact(gdrf_ctx* c, hipStream_t s) {
+  if (c->fact_pending) HIPCHK(hipStreamWaitEvent(s, c->ev_fact, 0));
+  return 0;
+}
+
 int gdrf_ws_copy(gdrf_ctx* c, int which, void* dst, int64_t nelem, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   void* p; int64_t n; int e;
   int rc = ws_lookup(c, which, &p, &n, &e);
   if (rc) return rc;
   if (nelem > n) return fail(-1, "gdrf_ws_copy", "nelem exceeds the buffer");
+  if ((rc = join_fact(c, (hipStream_t)stream))) return rc;
   HIPCHK(hipMemcpyAsync(dst, p, (size_t)nelem * e, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
@@ -347,24 +356,34 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
-  // K_uu(+jitter) -> Cholesky(flag) -> L, LT -> Linv, LinvT in the solve precision
+  // K_uu(+jitter) -> Cholesky(flag) -> L, LT -> Linv, LinvT in the solve precision.  The hyper-parameters and the cast of Z
+  // are refreshed on the caller's stream; the factorisation chain (one workgroup for most of its 1.7 ms) runs on the
+  // context's side stream so that what follows on the caller's stream and does not need L (the S / B_k transforms and the
+  // solve-precision K_nm of gdrf_step_local) overlaps it.  Every consumer of L calls join_fact() first.
   static int factorize(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
     const int Mp = c->Mp, M = c->M;
-    ScopedTimer tm(c, 15, s);
     dim3 g2((Mp + 255) / 256, Mp);
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     const int64_t nz = (int64_t)M * c->D;
     hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, nz, Z, Q(c->Zs));
-    HIPCHK(hipMemsetAsync(c->flag, 0, 32, s));
-    hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
-    HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, s));
-    if (chol_lds_bytes<TS>(M) > 48 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<TS>(M)));
-    hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), s, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
-    hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
-    hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, s, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
-    hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(1024), 0, s, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
-                       Q(c->LinvT));
+    HIPCHK(hipEventRecord(c->ev_fact0, s));
+    hipStream_t f = c->side;
+    HIPCHK(hipStreamWaitEvent(f, c->ev_fact0, 0));
+    {
+      ScopedTimer tm(c, 15, f);
+      HIPCHK(hipMemsetAsync(c->flag, 0, 32, f));
+      hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
+      HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, f));
+      if (chol_lds_bytes<TS>(M) > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<TS>(M)));
+      hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), f, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
+      hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
+      hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, f, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
+      hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(1024), 0, f, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
+                         Q(c->LinvT));
+    }
+    HIPCHK(hipEventRecord(c->ev_fact, f));
+    c->fact_pending = 1;
     LAUNCHCHK("factorize");
     return 0;
   }
@@ -482,6 +501,7 @@ template <typename T, typename TS> struct Impl {
     // (1) W = Knm Linv^T in the solve precision, stored in the N-side precision
     {
       if ((rc = knm_solve(c, X, n, s))) return rc;
+      if ((rc = join_fact(c, s))) return rc;          // W needs L^-1
       ScopedTimer tm(c, 3, s);
       FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
       hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
@@ -614,6 +634,7 @@ template <typename T, typename TS> struct Impl {
     const T* phib = redT + roff(c, 1);
     const T* Ak = redT + roff(c, 2);
     const T* GT = redT + roff(c, 3);
+    if ((rc = join_fact(c, s))) return rc;
     ScopedTimer tm(c, 13, s);
     dim3 g2((Mp + 255) / 256, Mp);
     // Cholesky / inverse backward in the solve precision
@@ -644,6 +665,7 @@ template <typename T, typename TS> struct Impl {
                      T* out, double* out_d, hipStream_t s) {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
     const T* U = params + poff(c, 3);
+    if (int rcj = join_fact(c, s)) return rcj;
     if (mode >= 2) hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, params + poff(c, 4), K, V, P(c->phi));
     hipLaunchKernelGGL((predict_coeff_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, K, Q(c->Cf));
     size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(TS);
@@ -764,6 +786,7 @@ int gdrf_predict(gdrf_ctx* c, const void* X, int64_t n, const void* Z, const voi
 int gdrf_chol_failed(gdrf_ctx* c, int* failed, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = join_fact(c, s)) return rc;
   HIPCHK(hipMemcpyAsync(failed, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return 0;
