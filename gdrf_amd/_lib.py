@@ -21,6 +21,8 @@ SIGNATURES = {
     "gdrf_stores_t": (_int, [_vp]),
     "gdrf_set_mfma_mode": (_int, [_vp, _int]),
     "gdrf_get_mfma_mode": (_int, [_vp]),
+    "gdrf_set_learn_inducing": (_int, [_vp, _int]),
+    "gdrf_inducing_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_ctx_destroy": (None, [_vp]),
     "gdrf_param_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_red_layout": (_int, [_vp, C.POINTER(_i64)]),

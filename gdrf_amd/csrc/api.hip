@@ -66,6 +66,7 @@ struct gdrf_ctx {
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
   hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join, ev_fact0, ev_fact;
   int fact_pending;           // a factorisation has been queued on the side stream: consumers wait for ev_fact
+  int learn_z; double* zpart; // learnable inducing inputs: per-row-tile partial sums [ceil(ncap/128)][M][D]
   std::vector<void*> allocs;
   // optional per-kernel HIP-event timing (gdrf_set_timing): events recorded on the launch stream
   int timing;
@@ -96,9 +97,10 @@ static int64_t poff(const gdrf_ctx* c, int which) {
   // flat parameter layout; every segment starts on a multiple of 4 elements
   const int64_t o_uloc = 4, o_phi = round_up(o_uloc + (int64_t)c->K * c->M, 4);
   const int64_t o_S = round_up(o_phi + (int64_t)c->K * c->V, 4);
-  const int64_t total = round_up(o_S + (int64_t)c->K * c->M * c->M, 4);
+  const int64_t o_Z = round_up(o_S + (int64_t)c->K * c->M * c->M, 4);          // unconstrained inducing inputs (M, D)
+  const int64_t total = round_up(o_Z + (int64_t)c->M * c->D, 4);
   switch (which) { case 0: return 0; case 1: return 1; case 2: return 2; case 3: return o_uloc; case 4: return o_phi;
-                   case 5: return o_S; default: return total; }
+                   case 5: return o_S; case 7: return o_Z; default: return total; }
 }
 static int64_t roff(const gdrf_ctx* c, int which) {
   const int64_t mm = (int64_t)c->Mp * c->Mp;
@@ -110,9 +112,10 @@ static int64_t roff(const gdrf_ctx* c, int which) {
 int gdrf_param_layout(const gdrf_ctx* c, int64_t out[7]) { for (int i = 0; i < 7; ++i) out[i] = poff(c, i); return 0; }
 int gdrf_red_layout(const gdrf_ctx* c, int64_t out[6]) {
   for (int i = 0; i < 5; ++i) out[i] = roff(c, i);
-  out[5] = 8;
+  out[5] = 8 + (int64_t)c->M * c->D;          // 8 scalars, then the (M, D) inducing-input sums (learnable inducing points)
   return 0;
 }
+int gdrf_inducing_layout(const gdrf_ctx* c, int64_t out[2]) { out[0] = poff(c, 7); out[1] = (int64_t)c->M * c->D; return 0; }
 
 // row blocks of the ubar partial kernel: ~1024 workgroups, multiples of its 256-row staging step
 static int64_t ubar_rows_per_block(int64_t n) { return std::max<int64_t>(256, round_up((n + 1023) / 1024, 256)); }
@@ -153,7 +156,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->bf16x6 = 0;
-  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0;
+  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -271,6 +274,19 @@ int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
     c->Wh = p; c->allocs.push_back(p);
   }
   c->bf16x6 = mode;
+  return 0;
+}
+int gdrf_set_learn_inducing(gdrf_ctx* c, int on) {
+  if (on != 0 && on != 1) return fail(-1, "gdrf_set_learn_inducing", "on must be 0 or 1");
+  HIPCHK(hipSetDevice(c->dev));
+  if (on && !c->zpart) {
+    void* p = nullptr;
+    const size_t bytes = (size_t)((c->ncap + GDRF_TILE - 1) / GDRF_TILE) * c->M * c->D * sizeof(double);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(zpart)", hipGetErrorString(e));
+    c->zpart = (double*)p; c->allocs.push_back(p);
+  }
+  c->learn_z = on;
   return 0;
 }
 int gdrf_get_mfma_mode(const gdrf_ctx* c) { return c->bf16x6; }
@@ -596,11 +612,19 @@ template <typename T, typename TS> struct Impl {
     // (4) kernel hyper-parameter partials through Knm (solve precision)
     {
       ScopedTimer tm(c, 8, s);
-      BwdKnmProb<TS, T> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
-                          c->dpart};
       const int64_t nb = nt_xcd_row_grid(rtiles, nct<TS>(c));
       if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
-      hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
+      if (c->learn_z) {
+        BwdKnmProb<TS, T, true> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs),
+                                  c->hyp, c->dpart, c->zpart};
+        hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T, true>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
+        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3((unsigned)((M * c->D + 255) / 256)), dim3(256), 0, s, (const double*)c->zpart, rtiles,
+                           (int64_t)M * c->D, redd + 8);
+      } else {
+        BwdKnmProb<TS, T> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
+                            c->dpart, nullptr};
+        hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
+      }
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 2, redd + 4);
     }
     LAUNCHCHK("backward");
@@ -651,6 +675,9 @@ template <typename T, typename TS> struct Impl {
     hipLaunchKernelGGL(kuu_bar_reduce_kernel<TS>, dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind,
                        c->hyp, c->dpart);
     hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)M, 2, c->dsmall);
+    if (c->learn_z)
+      hipLaunchKernelGGL((grad_z_kernel<TS, T>), dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp,
+                         redd + 8, -1.0 / n_global, grads + poff(c, 7));
     // Sbar_k = 2 A_k S_k (N-side precision: well conditioned)
     if ((rc = mm_nt<T>(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, s))) return rc;
     dim3 g3((M + 255) / 256, M, K);

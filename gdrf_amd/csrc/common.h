@@ -7,6 +7,7 @@
 #define GDRF_TILE 128          // output tile edge of both GEMM cores
 #define GDRF_KBYTES 128        // bytes of reduction index staged per row per chunk (NT core)
 #define GDRF_MPAD 32           // M is padded to a multiple of this in every workspace matrix
+#define GDRF_DMAX 4            // input dimensions supported (index columns of the reference's CSV)
 
 namespace gdrf {
 
@@ -99,6 +100,16 @@ template <typename T> __device__ __forceinline__ T dcov_dlogls_from_k(int kind, 
   if (kind == 2) { const T a = T(1.73205080756887729353) * r; return k / (T(1) + a) * a * T(1.73205080756887729353) * (r2 / r); }
   const T a = T(2.23606797749978969641) * r;
   return k / (T(1) + a + (T(5) / T(3)) * r * r) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
+}
+// d k / d r2 from an already evaluated k (r2 = squared distance / lengthscale^2): the factor of the gradient with respect
+// to an input point, d k(x,z)/d z_d = dcov_dr2 * d r2/d z_d = dcov_dr2 * 2 (z_d - x_d) / lengthscale^2
+template <typename T> __device__ __forceinline__ T dcov_dr2_from_k(int kind, T k, T r2) {
+  if (kind == 0) return T(-0.5) * k;
+  const T r = t_sqrt<T>(r2 + T(1e-12));
+  if (kind == 3) return -k / (T(2) * r);
+  if (kind == 2) { const T a = T(1.73205080756887729353) * r; return T(-1.5) * k / (T(1) + a); }
+  const T a = T(2.23606797749978969641) * r;
+  return -(T(5) / T(6)) * (T(1) + a) * k / (T(1) + a + (T(5) / T(3)) * r * r);
 }
 template <typename T> __device__ __forceinline__ T sqdist(const T* __restrict__ x, const T* __restrict__ z, int D) {
   T s = 0;

@@ -396,6 +396,35 @@ __global__ void kuu_bar_reduce_kernel(const T* __restrict__ Sp, const T* __restr
   if (threadIdx.x == 0) { part[2 * i] = s1; part[2 * i + 1] = s2; }
 }
 
+// gradient of the loss w.r.t. the unconstrained inducing inputs (interval(0,1) constraint = sigmoid; sparse_gdrf.py:79-88):
+//   Zbar[i][d] = 2/ls^2 * ( G[i][d] + 2 * sum_j Kuu_bar[i][j] * dk/dr2(z_i, z_j) * (z_id - z_jd) ),  Kuu_bar = (S' + S'^T)/2,
+// G = the observation-side sums of gemm_nt<BwdKnmProb<.., true>> (all-reduced), then the chain through z = sigmoid(u):
+// g = -1/N * Zbar * z (1 - z).  One block per inducing point.
+template <typename T, typename TP>
+__global__ void grad_z_kernel(const T* __restrict__ Sp, const T* __restrict__ Z, int M, int Mp, int D, int kind,
+                              const Hyper* __restrict__ h, const double* __restrict__ G, double neg_inv_n, TP* __restrict__ g) {
+  __shared__ double scratch[16];
+  const int i = blockIdx.x;
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  double hs[GDRF_DMAX];
+  for (int d = 0; d < GDRF_DMAX; ++d) hs[d] = 0;
+  for (int j = threadIdx.x; j < M; j += blockDim.x) {
+    if (j == i) continue;
+    const T kb = T(0.5) * (Sp[(int64_t)i * Mp + j] + Sp[(int64_t)j * Mp + i]);
+    const T r2 = sqdist<T>(Z + (int64_t)i * D, Z + (int64_t)j * D, D) * ils2;
+    const T w = kb * dcov_dr2_from_k<T>(kind, cov_from_r2<T>(kind, r2, var), r2);
+    for (int d = 0; d < D; ++d) hs[d] += (double)(w * (Z[(int64_t)i * D + d] - Z[(int64_t)j * D + d]));
+  }
+  for (int d = 0; d < D; ++d) {
+    const double hsum = block_sum(hs[d], scratch);
+    if (threadIdx.x == 0) {
+      const double z = (double)Z[(int64_t)i * D + d];
+      const double zbar = 2.0 * (double)ils2 * (G[(int64_t)i * D + d] + 2.0 * hsum);
+      g[(int64_t)i * D + d] = (TP)(neg_inv_n * zbar * z * (1.0 - z));
+    }
+  }
+}
+
 // gradient of the loss w.r.t. the unconstrained u_scale_tril from Sbar = 2 A_k S_k (already scaled by 2)
 template <typename T>
 __global__ void grad_s_kernel(const T* __restrict__ Sbar, const T* __restrict__ S, int M, int Mp, double neg_inv_n,

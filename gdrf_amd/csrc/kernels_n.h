@@ -9,7 +9,6 @@
 #include "gemm_nt.h"
 #include "kernels_mm.h"
 
-#define GDRF_DMAX 4
 
 namespace gdrf {
 
@@ -451,7 +450,9 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
 };
 
 // (4) Knm_bar = Wbar Linv (never stored) -> sum Knm_bar*Knm and sum Knm_bar*dKnm/dlog(ls) per workgroup
-template <typename T, typename TN> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
+// LZ: also the per-inducing-point sums  G[j][d] = sum_n Kbar[n][j] * dk/dr2(x_n, z_j) * (z_jd - x_nd)  that the gradient of
+// learnable inducing inputs needs (sparse_gdrf.py:79-88, fixed_inducing_points=False); one partial per (row tile, column).
+template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
@@ -461,8 +462,9 @@ template <typename T, typename TN> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
   const T* Knm;                    // [nrows][Mp] solve-precision K_nm (same buffer the forward consumed)
   const TN* X; const T* Z; const Hyper* h;
   double* part;                    // [gridDim.x][2]
+  double* zpart;                   // LZ: [row tiles][M][D]
   struct ACtx { const TN* p[NTCfg<T>::VPT]; };
-  struct ECtx { T s1, s2; };
+  struct ECtx { T s1, s2; T zs[LZ ? NTCfg<T>::NB : 1][LZ ? GDRF_DMAX : 1]; int n0; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
@@ -474,7 +476,15 @@ template <typename T, typename TN> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
       c.p[i] = (r < nrows) ? Wbar + r * Mp : nullptr;
     }
   }
-  __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const { e.s1 = 0; e.s2 = 0; }
+  __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
+    e.s1 = 0; e.s2 = 0; e.n0 = 0;
+    if constexpr (LZ) {
+#pragma unroll
+      for (int b = 0; b < NTCfg<T>::NB; ++b)
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) e.zs[b][d] = 0;
+    }
+  }
   using AVec = TN __attribute__((ext_vector_type(Vec16<T>::N)));        // same element count, N-side element type
   __device__ __forceinline__ AVec loadA(const ACtx& c, int i, int k, int, int) const {
     AVec t;
@@ -496,6 +506,7 @@ template <typename T, typename TN> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
   template <class Acc, int NB_>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
     const T ils2 = (T)h->inv_ls2;
+    e.n0 = n0;
     T z[4][GDRF_DMAX];
 #pragma unroll
     for (int b = 0; b < NTCfg<T>::NB; ++b) {
@@ -523,15 +534,50 @@ template <typename T, typename TN> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
           const T kv = Knm[m * Mp + n];
           e.s1 += acc[a][b][r] * kv;
           e.s2 += acc[a][b][r] * dcov_dlogls_from_k<T>(kind, kv, r2);
+          if constexpr (LZ) {
+            const T w = acc[a][b][r] * dcov_dr2_from_k<T>(kind, kv, r2);
+#pragma unroll
+            for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) e.zs[b][d] += w * (z[b][d] - x[d]);
+          }
         }
       }
   }
-  __device__ __forceinline__ void finish(int64_t, int, ECtx& e, char* smem, int, int, int) const {
+  __device__ __forceinline__ void finish(int64_t m0, int, ECtx& e, char* smem, int wr, int wc, int lane) const {
     double* scratch = reinterpret_cast<double*>(smem);
     __syncthreads();
     const double a = block_sum((double)e.s1, scratch);
     const double b = block_sum((double)e.s2, scratch);
     if (threadIdx.x == 0) { part[2 * (int64_t)blockIdx.x] = a; part[2 * (int64_t)blockIdx.x + 1] = b; }
+    if constexpr (LZ) {
+      // column sums: the 4 lane groups of a wave hold 16 rows each, the two waves wr = 0, 1 the two halves of the row tile
+      double* zb = reinterpret_cast<double*>(smem + 1024);       // [CW][DMAX]
+#pragma unroll
+      for (int bb = 0; bb < NTCfg<T>::NB; ++bb)
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) {
+          T v = e.zs[bb][d];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          e.zs[bb][d] = v;
+        }
+      __syncthreads();
+      if (wr == 1 && (lane >> 4) == 0) {
+#pragma unroll
+        for (int bb = 0; bb < NTCfg<T>::NB; ++bb)
+#pragma unroll
+          for (int d = 0; d < GDRF_DMAX; ++d) zb[nt_acc_col<T>(wc, bb, lane) * GDRF_DMAX + d] = (double)e.zs[bb][d];
+      }
+      __syncthreads();
+      if (wr == 0 && (lane >> 4) == 0 && m0 < nrows) {
+        const int64_t rt = m0 / GDRF_TILE;
+#pragma unroll
+        for (int bb = 0; bb < NTCfg<T>::NB; ++bb) {
+          const int cl = nt_acc_col<T>(wc, bb, lane), n = e.n0 + cl;
+          if (n < M)
+            for (int d = 0; d < D; ++d) zpart[(rt * M + n) * D + d] = (double)e.zs[bb][d] + zb[cl * GDRF_DMAX + d];
+        }
+      }
+    }
   }
 };
 

@@ -33,7 +33,7 @@ class Engine:
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
                  device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
-                 store_t="auto", mfma_mode: str = "auto"):
+                 store_t="auto", mfma_mode: str = "auto", learn_inducing: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -68,8 +68,14 @@ class Engine:
             _lib.check(self.lib.gdrf_set_mfma_mode(self.ctx, 1), "gdrf_set_mfma_mode")
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
+        zl = (C.c_int64 * 2)()
+        _lib.check(self.lib.gdrf_inducing_layout(self.ctx, zl), "gdrf_inducing_layout")
         self.layout = dict(log_lengthscale=lay[0], log_variance=lay[1], log_noise=lay[2], u_loc=lay[3], phi_unc=lay[4],
-                           u_scale_tril_unc=lay[5], total=lay[6])
+                           u_scale_tril_unc=lay[5], inducing_unc=zl[0], total=lay[6])
+        # fixed_inducing_points=False of the reference: Z = sigmoid(unconstrained block), refreshed before every evaluation
+        self.learn_inducing = bool(learn_inducing)
+        if self.learn_inducing:
+            _lib.check(self.lib.gdrf_set_learn_inducing(self.ctx, 1), "gdrf_set_learn_inducing")
         red = (C.c_int64 * 6)()
         _lib.check(self.lib.gdrf_red_layout(self.ctx, red), "gdrf_red_layout")
         self.red_layout = dict(ubar=red[0], phibar=red[1], A=red[2], GT=red[3], total_T=red[4], total_d=red[5])
@@ -110,6 +116,8 @@ class Engine:
             return buf[o:o + K * V].view(K, V)
         if name == "u_scale_tril_unc":
             return buf[o:o + K * M * M].view(K, M, M)
+        if name == "inducing_unc":
+            return buf[o:o + M * self.D].view(M, self.D)
         raise KeyError(name)
 
     PARAM_NAMES = ("log_lengthscale", "log_variance", "log_noise", "u_loc", "phi_unc", "u_scale_tril_unc")
@@ -120,7 +128,17 @@ class Engine:
     def set_inducing_points(self, Z: torch.Tensor):
         Z = Z.to(device=self.device, dtype=self.dtype).contiguous()
         assert Z.shape == (self.M, self.D), f"inducing points must be ({self.M},{self.D}), got {tuple(Z.shape)}"
-        self.Z = Z
+        self.Z = Z.clone()
+        if self.learn_inducing:
+            # transform_to(interval(0, 1)).inv: logit of the value clamped to [tiny, 1 - eps] (torch SigmoidTransform._inverse)
+            fi = torch.finfo(self.dtype)
+            y = self.Z.clamp(min=fi.tiny, max=1.0 - fi.eps)
+            self.view("inducing_unc").copy_(y.log() - (-y).log1p())
+
+    def refresh_inducing(self):
+        """Z = sigmoid(unconstrained block) when the inducing inputs are learnable (no-op otherwise)."""
+        if self.learn_inducing:
+            torch.sigmoid(self.view("inducing_unc"), out=self.Z)
 
     def set_dirichlet(self, alpha: torch.Tensor):
         a = alpha.detach().to("cpu", torch.float64).contiguous()
@@ -247,6 +265,7 @@ class Engine:
         if tuple(eps.shape[1:]) != (self.K, n) or eps.dtype != self.dtype or not eps.is_contiguous() or eps.device != self.device:
             raise ValueError(f"eps must be a contiguous ([P,]{self.K},{n}) {self.dtype} tensor on {self.device}")
         s = _stream_ptr(self.device)
+        self.refresh_inducing()
         llc = self.ll_const(ws) if ll_const is None else ll_const
         ng = float(n if n_global is None else n_global)
         guess = self._guess_level if (force_level is None and self.speculate) else None
@@ -347,6 +366,7 @@ class Engine:
     def predict(self, xs: torch.Tensor, mode: int, ws: Optional[torch.Tensor] = None):
         self._chk_rows(xs, ws)
         n = xs.shape[0]
+        self.refresh_inducing()
         self.factorize()
         out = None
         if mode == 0:

@@ -24,6 +24,7 @@ _PARAM_KEYS = {  # state_dict names follow pyro's "<name>_unconstrained" convent
     "u_loc": "u_loc_unconstrained",
     "phi_unc": "_word_topic_matrix_map_unconstrained",
     "u_scale_tril_unc": "u_scale_tril_unconstrained",
+    "inducing_unc": "_inducing_points_unconstrained",          # only when fixed_inducing_points=False
 }
 
 
@@ -99,9 +100,6 @@ class SparseMultinomialGDRF:
                                       "(gdrf/models/abstract_gdrf.py:17-22)")
         if not whiten:
             raise NotImplementedError("whiten=False (SURVEY.md 8(f) item 4)")
-        if not fixed_inducing_points:
-            raise NotImplementedError("learnable inducing points (fixed_inducing_points=False) are SURVEY.md 8(f) item 4; "
-                                      "train() defaults to fixed_inducing_points=True (gdrf/train_script.py:115)")
         if randomize_metric is not None:
             raise NotImplementedError("randomize_metric")
         if not isinstance(kernel, Kernel):
@@ -121,7 +119,7 @@ class SparseMultinomialGDRF:
         self._upper = torch.tensor([b[1] for b in self._world], dtype=torch.float64)
         self._delta = self._upper - self._lower
         self._jitter, self._maxjitter, self._whiten = float(jitter), int(maxjitter), True
-        self._fixed_inducing_points = True
+        self._fixed_inducing_points = bool(fixed_inducing_points)   # False: Z is an interval(0,1)-constrained parameter
         if isinstance(dirichlet_param, float):
             dirichlet_param = torch.tensor(dirichlet_param)
         self._dirichlet_param = validate_dirichlet_param(dirichlet_param, self._K, self._V)
@@ -159,7 +157,8 @@ class SparseMultinomialGDRF:
         if e is not None and n <= e.n_cap:
             return e
         new = Engine(n, self.M, self._K, self._V, self.D, dtype=self.dtype, kernel=self._kernel.name, device=self.device,
-                     jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32, mfma_mode=self._mfma_mode)
+                     jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32, mfma_mode=self._mfma_mode,
+                     learn_inducing=not self._fixed_inducing_points)
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
         if e is None:
@@ -186,6 +185,12 @@ class SparseMultinomialGDRF:
             L = eng.workspace("L").to(eng.dtype)
             unc = L.tril(-1) + torch.diag(L.diagonal().log())             # lower_cholesky transform inverse
             eng.view("u_scale_tril_unc").copy_(unc.unsqueeze(0).expand(self._K, -1, -1))
+
+    @property
+    def inducing_points(self) -> torch.Tensor:
+        """(M, D) inducing inputs in the scaled world; the interval(0,1)-constrained value when they are learnable."""
+        self._engine.refresh_inducing()
+        return self._engine.Z
 
     @property
     def K(self):
@@ -295,13 +300,18 @@ class SparseMultinomialGDRF:
 
     # ------------------------------------------------------------------ state (train_script.py:338-363,490-506)
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        v = self._engine.named_views()
-        return {_PARAM_KEYS[n]: v[n].detach().clone() for n in self._engine.PARAM_NAMES}
+        return {_PARAM_KEYS[n]: self._engine.view(n).detach().clone() for n in self._param_names()}
+
+    def _param_names(self):
+        names = tuple(self._engine.PARAM_NAMES)
+        return names if self._fixed_inducing_points else names + ("inducing_unc",)
 
     def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True):
-        v = self._engine.named_views()
+        v = dict(self._engine.named_views())
+        if not self._fixed_inducing_points:
+            v["inducing_unc"] = self._engine.view("inducing_unc")
         missing = []
-        for n in self._engine.PARAM_NAMES:
+        for n in self._param_names():
             key = _PARAM_KEYS[n]
             if key not in state:
                 missing.append(key)
@@ -317,7 +327,8 @@ class SparseMultinomialGDRF:
         return missing
 
     def parameters(self):
-        return list(self._engine.named_views().values())
+        ps = list(self._engine.named_views().values())
+        return ps if self._fixed_inducing_points else ps + [self._engine.view("inducing_unc")]
 
     def float(self):
         return self

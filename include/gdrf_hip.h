@@ -51,6 +51,15 @@ int gdrf_stores_t(const gdrf_ctx* ctx);
  * Wbar form (GDRF_STORE_T_OFF); a fresh context is in mode 0, gdrf_amd.Engine selects 1 for float32 by default. */
 int gdrf_set_mfma_mode(gdrf_ctx* ctx, int mode);
 int gdrf_get_mfma_mode(const gdrf_ctx* ctx);
+/* Learnable inducing inputs (gdrf/models/sparse_gdrf.py:79-88, fixed_inducing_points=False: a PyroParam under
+ * stack([interval(0, 1)] * D), i.e. Z = sigmoid(unconstrained)).  The flat parameter vector always carries an (M, D)
+ * block for the unconstrained values, gdrf_inducing_layout -> {offset, M*D}; the caller evaluates Z = sigmoid(block) and
+ * passes it as Z_dev as before.  With on = 1, gdrf_step_local additionally accumulates
+ * G[j][d] = sum_n Kbar_nm[n][j] dk/dr2 (z_jd - x_nd) into red_d[8 + j*D + d] (all-reduced with the rest) and
+ * gdrf_step_finish writes d loss / d unconstrained into the block of grads (K_nm and K_uu paths, sigmoid Jacobian);
+ * with on = 0 (default) that block of grads stays zero. */
+int gdrf_set_learn_inducing(gdrf_ctx* ctx, int on);
+int gdrf_inducing_layout(const gdrf_ctx* ctx, int64_t out[2]);
 void gdrf_ctx_destroy(gdrf_ctx* ctx);
 
 /* Flat unconstrained-parameter vector (the PyroParam storage of gdrf/models/sparse_gdrf.py:96-122

@@ -160,7 +160,7 @@ class RefShapedGDRF:
     def __init__(self, xs, ws, *, kind="rbf", K=3, n_points=(8, 4), lengthscale=0.1, variance=25.0,
                  dirichlet_param=0.01, jitter=1e-8, maxjitter=15, noise=1.0, dtype=torch.float64,
                  Z: Optional[torch.Tensor] = None, optimizer="adam", lr=1e-3,
-                 force_jitter_level: Optional[int] = None):
+                 force_jitter_level: Optional[int] = None, learn_inducing: bool = False):
         self.dtype = dtype
         self.kind = kind
         self.K = K
@@ -189,6 +189,11 @@ class RefShapedGDRF:
             "log_noise": torch.tensor(float(noise), dtype=dtype).log().clone(),
             "phi_unc": wt.log().clone(),                  # simplex transform inverse = log
         }
+        self.learn_inducing = bool(learn_inducing)
+        if self.learn_inducing:
+            # sparse_gdrf.py:79-88: PyroParam(scaled points, constraint=stack([interval(0, 1)] * D)); the stored value is
+            # transform_to(interval).inv(Z) = logit of Z clamped to [tiny, 1 - eps] (torch SigmoidTransform._inverse)
+            self.params["inducing_unc"] = transform_to(constraints.interval(0.0, 1.0)).inv(self.Z).clone()
         for p in self.params.values():
             p.requires_grad_(True)
         self.optimizer_name = optimizer
@@ -198,6 +203,12 @@ class RefShapedGDRF:
         self.last_terms: Dict[str, float] = {}
 
     # ---- constrained views -------------------------------------------------
+    def inducing(self) -> torch.Tensor:
+        """The (M, D) inducing inputs in the scaled world: fixed, or the interval(0,1)-constrained parameter."""
+        if self.learn_inducing:
+            return transform_to(constraints.interval(0.0, 1.0))(self.params["inducing_unc"])
+        return self.Z
+
     def constrained(self):
         p = self.params
         return dict(
@@ -210,7 +221,8 @@ class RefShapedGDRF:
         )
 
     def _luu(self, c):
-        Kuu = kernel_matrix(self.kind, self.Z, self.Z, c["lengthscale"], c["variance"]).contiguous()
+        Zc = self.inducing()
+        Kuu = kernel_matrix(self.kind, Zc, Zc, c["lengthscale"], c["variance"]).contiguous()
         L, lvl = jittercholesky(Kuu, self.M, self.jitter, self.maxjitter, force_level=self.force_jitter_level)
         self.last_jitter_level = lvl
         return L
@@ -224,14 +236,14 @@ class RefShapedGDRF:
         c = self.constrained()
         # guide: sparse_gdrf.py:375-409
         Luu = self._luu(c)
-        f_loc, f_var = conditional(self.kind, xs, self.Z, c["lengthscale"], c["variance"],
+        f_loc, f_var = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
                                    c["u_loc"], c["u_scale_tril"], Luu)
         q_mu = Normal(f_loc, f_var)                       # Q1: variance passed as scale
         mu = f_loc + f_var * eps                          # rsample with injected eps
         lq_mu = q_mu.log_prob(mu).sum()
         # model (replayed with mu, phi): sparse_gdrf.py:323-373
         Luu2 = self._luu(c)
-        f_loc2, f_var2 = conditional(self.kind, xs, self.Z, c["lengthscale"], c["variance"],
+        f_loc2, f_var2 = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
                                      c["u_loc"], c["u_scale_tril"], Luu2)
         lp_mu = Normal(f_loc2, f_var2 + c["noise"]).log_prob(mu).sum()
         lp_phi = Dirichlet(self.alpha).log_prob(c["phi"]).sum()
@@ -283,7 +295,7 @@ class RefShapedGDRF:
         xs = self.xs if xs is None else torch.as_tensor(xs).to(self.dtype)
         c = self.constrained()
         Luu = self._luu(c)
-        f_loc, _ = conditional(self.kind, xs, self.Z, c["lengthscale"], c["variance"],
+        f_loc, _ = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
                                c["u_loc"], c["u_scale_tril"], Luu)
         return f_loc
 

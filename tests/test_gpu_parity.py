@@ -305,3 +305,61 @@ def test_speculative_jitter_level_gives_identical_steps(dtype):
     for mode in ("speculate", "wrong_guess"):
         assert torch.equal(runs[mode][0], runs["sync"][0]), mode
         assert runs[mode][1] == runs["sync"][1] and runs[mode][2] == runs["sync"][2], mode
+
+
+# ---- learnable inducing inputs (fixed_inducing_points=False; gdrf/models/sparse_gdrf.py:79-88) ----------------------------
+LZ_CASES = [dict(kind="rbf"), dict(kind="matern52", lengthscale=0.3), dict(kind="matern32", lengthscale=0.3),
+            dict(kind="exponential", lengthscale=0.4), dict(kind="rbf", one_d=True, n_points=(10,), lengthscale=0.2)]
+
+
+@pytest.mark.parametrize("case", LZ_CASES, ids=lambda c: c["kind"] + ("_1d" if c.get("one_d") else ""))
+def test_learnable_inducing_gradient_matches_autograd(case):
+    """d loss / d unconstrained inducing inputs (K_nm path in bwd_knm, K_uu path and sigmoid Jacobian in step_finish) and every
+    other gradient, fp64, against torch autograd through the reference-shaped oracle."""
+    kw = dict(W=24, H=15, V=10, K=3, n_points=(5, 4), jitter=1e-6, lengthscale=0.25)
+    kw.update(case)
+    m, eps = make_oracle(dtype=torch.float64, learn_inducing=True, random_inducing=True, **kw)
+    loss, grads = m.loss_and_grads(eps)
+    eng = engine_from_oracle(m)
+    assert eng.learn_inducing
+    eng.loss_and_grads(dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=m.last_jitter_level)
+    out = eng.read_out()
+    assert abs(out["loss"] - float(loss)) < LOSS_TOL_VS_TORCH * abs(float(loss))
+    assert torch.allclose(eng.Z.cpu(), m.inducing().detach(), rtol=0, atol=1e-15)
+    gz = eng.view("inducing_unc", eng.grads).cpu().numpy()
+    # exponential: 1/r in dk/dr2; 1-D: ten random points on a line give a badly conditioned K_uu, which amplifies the
+    # difference between the oracle's expanded-form distance and the direct (x-z)^2 here (measured 5e-7)
+    tol = 1e-6 if case["kind"] == "exponential" else (5e-6 if case.get("one_d") else 1e-8)
+    assert relerr(gz, grads["inducing_unc"].numpy()) < tol
+    for name in eng.PARAM_NAMES:
+        got, ref = eng.view(name, eng.grads).cpu().numpy(), grads[name].numpy()
+        assert np.abs(got - ref).max() < max(tol, 1e-8) * max(np.abs(ref).max(), 1e-9), name      # some blocks are exactly 0
+
+
+def test_learnable_inducing_adam_steps_follow_the_oracle():
+    """Five Adam steps with Z learnable: parameters (incl. the unconstrained inducing block) track the oracle in fp64, and the
+    default fp32 build (f64 solve, bf16x6 contractions) gives the same Z gradient to fp32 accuracy at identical parameters."""
+    m, eps = make_oracle(dtype=torch.float64, learn_inducing=True, random_inducing=True, W=24, H=15, V=10, K=3, n_points=(5, 4),
+                         jitter=1e-6, lengthscale=0.25, lr=1e-2)
+    eng = engine_from_oracle(m)
+    xs, ws, e = dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng)
+    eng32 = engine_from_oracle(m, dtype=torch.float32)
+    eng32.loss_and_grads(dev(m.xs, eng32), dev(m.ws, eng32, torch.int32), dev(eps, eng32))
+    _, g0 = m.loss_and_grads(eps)
+    assert relerr(eng32.view("inducing_unc", eng32.grads).cpu().numpy(), g0["inducing_unc"].numpy()) < 2e-3
+    for _ in range(5):
+        m.step(eps)
+        eng.loss_and_grads(xs, ws, e)
+        eng.adam("adam", 1e-2)
+    assert relerr(eng.view("inducing_unc").cpu().numpy(), m.params["inducing_unc"].detach().numpy()) < 1e-7
+    for name in eng.PARAM_NAMES:
+        assert relerr(eng.view(name).cpu().numpy(), m.params[name].detach().numpy()) < 1e-7, name
+    z0 = torch.sigmoid(transform_inv_check(m))
+    assert not torch.allclose(m.inducing().detach(), z0)        # the inducing inputs did move
+
+
+def transform_inv_check(m):
+    # the oracle's initial unconstrained block is recoverable from its fixed copy of Z
+    fi = torch.finfo(m.dtype)
+    y = m.Z.clamp(min=fi.tiny, max=1.0 - fi.eps)
+    return y.log() - (-y).log1p()

@@ -144,3 +144,36 @@ def test_train_driver_full_batch_and_streaming():
                     streaming_inference=mode, streaming_size=3, kernel_lengthscale=0.2, optimizer_lr=0.01, jitter=1e-6,
                     perplexity_every=20)
         assert out["history"].shape[0] == 60 and np.isfinite(out["history"][:, 0]).all()
+
+
+def test_learnable_inducing_points_like_the_reference_default():
+    """SparseMultinomialGDRF(..., fixed_inducing_points=False) (the reference constructor's default, sparse_gdrf.py:24,79-88):
+    the inducing inputs are an interval(0,1)-constrained parameter trained with everything else; random interior init."""
+    from gdrf_amd import poutine
+    from gdrf_amd.infer import SVI, OBJECTIVE_DICT
+    from gdrf_amd.kernels import KERNEL_DICT
+    from gdrf_amd.models import GDRF_MODEL_DICT
+    from gdrf_amd.optim import OPTIMIZER_DICT
+    xs_np, ws_np, _ = synth_circles(30, 20, 12, 3, seed=5)
+    device = "cuda:0"
+    xs, ws = torch.from_numpy(xs_np).float().to(device), torch.from_numpy(ws_np).int().to(device)
+    kern = KERNEL_DICT["rbf"](input_dim=2, lengthscale=torch.tensor(0.2), variance=torch.tensor(25.0)).to(device)
+    model = GDRF_MODEL_DICT["sparsemultinomialgdrf"](
+        xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=kern, num_observation_categories=12, device=device,
+        num_topic_categories=3, dirichlet_param=0.01, n_points=[5, 4], fixed_inducing_points=False, inducing_init="random",
+        maxjitter=15, jitter=1e-6, seed=5)
+    z0 = model.inducing_points.clone()
+    assert z0.shape == (20, 2) and float(z0.min()) >= 0.0 and float(z0.max()) <= 1.0
+    assert "_inducing_points_unconstrained" in model.state_dict() and len(model.parameters()) == 7
+    svi = SVI(model=poutine.scale(scale=1.0 / len(xs))(model.model), guide=poutine.scale(scale=1.0 / len(xs))(model.guide),
+              optim=OPTIMIZER_DICT["adam"]({"lr": 0.02}), loss=OBJECTIVE_DICT["elbo"](max_plate_nesting=1, num_particles=1))
+    p0 = float(model.perplexity(xs, ws).item())
+    losses = [svi.step(xs=xs, ws=ws, subsample=False) for _ in range(30)]
+    z1 = model.inducing_points
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert float((z1 - z0).abs().max()) > 1e-4 and float(z1.min()) >= 0.0 and float(z1.max()) <= 1.0
+    assert float(model.perplexity(xs, ws).item()) < p0
+    # round trip through the checkpoint surface
+    sd = model.state_dict()
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert torch.equal(model.inducing_points, z1)

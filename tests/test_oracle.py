@@ -154,3 +154,26 @@ def test_oracle_reproduces_golden_runs(name):
     losses = [m.step(eps[s]) for s in range(eps.shape[0])]
     assert np.allclose(losses, g["losses"], rtol=1e-11)
     assert np.allclose(m.topic_probs().numpy(), g["topic_probs"], atol=1e-11)
+
+
+def test_learnable_inducing_inputs_oracle():
+    """fixed_inducing_points=False (sparse_gdrf.py:79-88): Z = interval(0,1)-transform of an unconstrained block.  The
+    constrained value starts at the given points, and the autograd gradient w.r.t. the block agrees with a central
+    finite difference of the loss (pins the oracle path the GPU test compares against)."""
+    from tests._util import make_oracle
+    m, eps = make_oracle(dtype=torch.float64, learn_inducing=True, random_inducing=True, W=10, H=8, V=6, K=2, n_points=(3, 3),
+                         jitter=1e-6, lengthscale=0.3)
+    assert torch.allclose(m.inducing().detach(), m.Z, atol=1e-14)
+    _, g = m.loss_and_grads(eps)
+    for idx in [(0, 0), (4, 1), (8, 0)]:
+        h = 1e-6
+        with torch.no_grad():
+            m.params["inducing_unc"][idx] += h
+        lp = float(m.loss(eps))
+        with torch.no_grad():
+            m.params["inducing_unc"][idx] -= 2 * h
+        lm = float(m.loss(eps))
+        with torch.no_grad():
+            m.params["inducing_unc"][idx] += h
+        fd = (lp - lm) / (2 * h)
+        assert abs(fd - float(g["inducing_unc"][idx])) < 1e-6 * max(1.0, abs(fd)), (idx, fd, float(g["inducing_unc"][idx]))
