@@ -146,7 +146,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   if (K > GDRF_KMAX) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 32 not supported");
   if (D > GDRF_DMAX) return fail(-1, "gdrf_ctx_create", "more than 4 input dimensions not supported");
   if (dtype != GDRF_F32 && dtype != GDRF_F64 && dtype != GDRF_F32_PURE) return fail(-1, "gdrf_ctx_create", "dtype");
-  if (kernel_id < GDRF_RBF || kernel_id > GDRF_EXPONENTIAL) return fail(-1, "gdrf_ctx_create", "kernel_id");
+  if (kernel_id < GDRF_RBF || kernel_id > GDRF_RATIONALQUADRATIC) return fail(-1, "gdrf_ctx_create", "kernel_id");
   HIPCHK(hipSetDevice(device));
   gdrf_ctx* c = new gdrf_ctx();
   c->dev = device; c->M = M; c->Mp = (int)round_up(M, GDRF_MPAD); c->K = K; c->V = V; c->D = D;
@@ -198,7 +198,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->erows_grid_cap = 1024;
   AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
   const int64_t rtiles = (n_cap + GDRF_TILE - 1) / GDRF_TILE;
-  c->dpart_len = std::max<int64_t>(((rtiles + 8) * ((c->Mp + 63) / 64) + 16) * 2, 8192);
+  c->dpart_len = std::max<int64_t>(((rtiles + 8) * ((c->Mp + 63) / 64) + 16) * 3, 8192);
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
@@ -613,7 +613,7 @@ template <typename T, typename TS> struct Impl {
     {
       ScopedTimer tm(c, 8, s);
       const int64_t nb = nt_xcd_row_grid(rtiles, nct<TS>(c));
-      if (2 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
+      if (3 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");
       if (c->learn_z) {
         BwdKnmProb<TS, T, true> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs),
                                   c->hyp, c->dpart, c->zpart};
@@ -625,7 +625,7 @@ template <typename T, typename TS> struct Impl {
                             c->dpart, nullptr};
         hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
       }
-      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 2, redd + 4);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 3, redd + 4);      // red_d[4..6]
     }
     LAUNCHCHK("backward");
     // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
@@ -674,7 +674,7 @@ template <typename T, typename TS> struct Impl {
     if ((rc = mm_nt<TS>(c, Q(c->LinvT), 0, Q(c->t0), 0, Q(c->t1), 0, TS(1), 1, s))) return rc;
     hipLaunchKernelGGL(kuu_bar_reduce_kernel<TS>, dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind,
                        c->hyp, c->dpart);
-    hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)M, 2, c->dsmall);
+    hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)M, 3, c->dsmall);
     if (c->learn_z)
       hipLaunchKernelGGL((grad_z_kernel<TS, T>), dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp,
                          redd + 8, -1.0 / n_global, grads + poff(c, 7));

@@ -74,9 +74,11 @@ template <> __device__ __forceinline__ double t_eps<double>() { return 2.2204460
 // kind 0 = RBF, 1 = Matern52.  r2 is the squared distance scaled by 1/lengthscale^2.
 struct KParams { double inv_ls2; double var; };     // device-side hyper-parameters (double, cast per use)
 
-// kind: 0 RBF, 1 Matern52, 2 Matern32, 3 Exponential  (pyro.contrib.gp.kernels.isotropic)
-template <typename T> __device__ __forceinline__ T cov_from_r2(int kind, T r2, T var) {
+// kind: 0 RBF, 1 Matern52, 2 Matern32, 3 Exponential, 4 RationalQuadratic  (pyro.contrib.gp.kernels.isotropic)
+// RationalQuadratic: k = var * (1 + r2 / (2 alpha))^(-alpha), alpha = scale_mixture (ignored by the other kinds)
+template <typename T> __device__ __forceinline__ T cov_from_r2(int kind, T r2, T var, T alpha = T(1)) {
   if (kind == 0) return var * t_exp<T>(T(-0.5) * r2);
+  if (kind == 4) return var * t_exp<T>(-alpha * t_log<T>(T(1) + r2 * (T(0.5) / alpha)));
   const T r = t_sqrt<T>(r2 + T(1e-12));
   if (kind == 3) return var * t_exp<T>(-r);
   if (kind == 2) { const T a = T(1.73205080756887729353) * r; return var * (T(1) + a) * t_exp<T>(-a); }
@@ -84,8 +86,9 @@ template <typename T> __device__ __forceinline__ T cov_from_r2(int kind, T r2, T
   return var * (T(1) + a + (T(5) / T(3)) * r * r) * t_exp<T>(-a);
 }
 // d k / d log(lengthscale)
-template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T r2, T var) {
+template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T r2, T var, T alpha = T(1)) {
   if (kind == 0) return k * r2;
+  if (kind == 4) return k * r2 / (T(1) + r2 * (T(0.5) / alpha));
   const T r = t_sqrt<T>(r2 + T(1e-12));
   if (kind == 3) return k * (r2 / r);
   if (kind == 2) { const T a = T(1.73205080756887729353) * r; return var * t_exp<T>(-a) * a * T(1.73205080756887729353) * (r2 / r); }
@@ -93,8 +96,9 @@ template <typename T> __device__ __forceinline__ T dcov_dlogls(int kind, T k, T 
   return var * t_exp<T>(-a) * (a / T(3)) * (T(1) + a) * T(2.23606797749978969641) * (r2 / r);
 }
 // the same derivative from an already evaluated k (no second exponential): exp(-a) = k / (var (1 + a + 5/3 r^2))
-template <typename T> __device__ __forceinline__ T dcov_dlogls_from_k(int kind, T k, T r2) {
+template <typename T> __device__ __forceinline__ T dcov_dlogls_from_k(int kind, T k, T r2, T alpha = T(1)) {
   if (kind == 0) return k * r2;
+  if (kind == 4) return k * r2 / (T(1) + r2 * (T(0.5) / alpha));
   const T r = t_sqrt<T>(r2 + T(1e-12));
   if (kind == 3) return k * (r2 / r);
   if (kind == 2) { const T a = T(1.73205080756887729353) * r; return k / (T(1) + a) * a * T(1.73205080756887729353) * (r2 / r); }
@@ -103,13 +107,21 @@ template <typename T> __device__ __forceinline__ T dcov_dlogls_from_k(int kind, 
 }
 // d k / d r2 from an already evaluated k (r2 = squared distance / lengthscale^2): the factor of the gradient with respect
 // to an input point, d k(x,z)/d z_d = dcov_dr2 * d r2/d z_d = dcov_dr2 * 2 (z_d - x_d) / lengthscale^2
-template <typename T> __device__ __forceinline__ T dcov_dr2_from_k(int kind, T k, T r2) {
+template <typename T> __device__ __forceinline__ T dcov_dr2_from_k(int kind, T k, T r2, T alpha = T(1)) {
   if (kind == 0) return T(-0.5) * k;
+  if (kind == 4) return T(-0.5) * k / (T(1) + r2 * (T(0.5) / alpha));
   const T r = t_sqrt<T>(r2 + T(1e-12));
   if (kind == 3) return -k / (T(2) * r);
   if (kind == 2) { const T a = T(1.73205080756887729353) * r; return T(-1.5) * k / (T(1) + a); }
   const T a = T(2.23606797749978969641) * r;
   return -(T(5) / T(6)) * (T(1) + a) * k / (T(1) + a + (T(5) / T(3)) * r * r);
+}
+// d k / d log(alpha) of the RationalQuadratic kernel (0 for the others): with u = r2 / (2 alpha),
+// d/d alpha [-alpha log(1 + u)] = -log(1 + u) + u / (1 + u)
+template <typename T> __device__ __forceinline__ T dcov_dlogalpha_from_k(int kind, T k, T r2, T alpha) {
+  if (kind != 4) return T(0);
+  const T u = r2 * (T(0.5) / alpha);
+  return k * alpha * (u / (T(1) + u) - t_log<T>(T(1) + u));
 }
 template <typename T> __device__ __forceinline__ T sqdist(const T* __restrict__ x, const T* __restrict__ z, int D) {
   T s = 0;

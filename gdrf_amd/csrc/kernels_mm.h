@@ -13,13 +13,13 @@
 namespace gdrf {
 
 // hyper-parameter block kept on the device (double): filled by prep_hyper
-struct Hyper { double ls, var, noise, inv_ls2; };
+struct Hyper { double ls, var, noise, inv_ls2, alpha; };     // alpha: RationalQuadratic scale_mixture (parameter slot 3)
 
 template <typename T>
 __global__ void prep_hyper_kernel(const T* __restrict__ params, Hyper* h) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double ls = exp((double)params[0]), var = exp((double)params[1]), noise = exp((double)params[2]);
-    h->ls = ls; h->var = var; h->noise = noise; h->inv_ls2 = 1.0 / (ls * ls);
+    h->ls = ls; h->var = var; h->noise = noise; h->inv_ls2 = 1.0 / (ls * ls); h->alpha = exp((double)params[3]);
   }
 }
 
@@ -39,7 +39,7 @@ __global__ void kuu_kernel(const T* __restrict__ Z, int M, int Mp, int D, int ki
   T v = 0;
   if (i < M && j < M) {
     const T r2 = sqdist<T>(Z + (int64_t)i * D, Z + (int64_t)j * D, D) * (T)h->inv_ls2;
-    v = cov_from_r2<T>(kind, r2, (T)h->var);
+    v = cov_from_r2<T>(kind, r2, (T)h->var, (T)h->alpha);
     if (i == j) v += (T)jitter;
   }
   Kuu[(int64_t)i * Mp + j] = v;
@@ -376,24 +376,27 @@ __global__ void phi_tril_kernel(const T* __restrict__ Q, int Mp, T* __restrict__
   const T q = Q[(int64_t)i * Mp + j];
   P[(int64_t)i * Mp + j] = (j < i) ? q : ((j == i) ? T(0.5) * q : T(0));
 }
-// sum_{ij} Kuu_bar * K0  and  sum_{ij} Kuu_bar * dK0/dlog(ls), Kuu_bar = (S' + S'^T)/2 ; one partial pair per block
+// sum_{ij} Kuu_bar * K0,  sum_{ij} Kuu_bar * dK0/dlog(ls)  and  sum_{ij} Kuu_bar * dK0/dlog(alpha), Kuu_bar = (S' + S'^T)/2 ;
+// one partial triple per block
 template <typename T>
 __global__ void kuu_bar_reduce_kernel(const T* __restrict__ Sp, const T* __restrict__ Z, int M, int Mp, int D, int kind,
                                       const Hyper* __restrict__ h, double* __restrict__ part) {
   __shared__ double scratch[16];
   const int i = blockIdx.x;
-  double s1 = 0, s2 = 0;
-  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  double s1 = 0, s2 = 0, s3 = 0;
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2, al = (T)h->alpha;
   for (int j = threadIdx.x; j < M; j += blockDim.x) {
     const T kb = T(0.5) * (Sp[(int64_t)i * Mp + j] + Sp[(int64_t)j * Mp + i]);
     const T r2 = sqdist<T>(Z + (int64_t)i * D, Z + (int64_t)j * D, D) * ils2;
-    const T k0 = cov_from_r2<T>(kind, r2, var);
+    const T k0 = cov_from_r2<T>(kind, r2, var, al);
     s1 += (double)(kb * k0);
-    s2 += (double)(kb * dcov_dlogls<T>(kind, k0, r2, var));
+    s2 += (double)(kb * dcov_dlogls<T>(kind, k0, r2, var, al));
+    s3 += (double)(kb * dcov_dlogalpha_from_k<T>(kind, k0, r2, al));
   }
   s1 = block_sum(s1, scratch);
   s2 = block_sum(s2, scratch);
-  if (threadIdx.x == 0) { part[2 * i] = s1; part[2 * i + 1] = s2; }
+  s3 = block_sum(s3, scratch);
+  if (threadIdx.x == 0) { part[3 * i] = s1; part[3 * i + 1] = s2; part[3 * i + 2] = s3; }
 }
 
 // gradient of the loss w.r.t. the unconstrained inducing inputs (interval(0,1) constraint = sigmoid; sparse_gdrf.py:79-88):
@@ -405,14 +408,14 @@ __global__ void grad_z_kernel(const T* __restrict__ Sp, const T* __restrict__ Z,
                               const Hyper* __restrict__ h, const double* __restrict__ G, double neg_inv_n, TP* __restrict__ g) {
   __shared__ double scratch[16];
   const int i = blockIdx.x;
-  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2, al = (T)h->alpha;
   double hs[GDRF_DMAX];
   for (int d = 0; d < GDRF_DMAX; ++d) hs[d] = 0;
   for (int j = threadIdx.x; j < M; j += blockDim.x) {
     if (j == i) continue;
     const T kb = T(0.5) * (Sp[(int64_t)i * Mp + j] + Sp[(int64_t)j * Mp + i]);
     const T r2 = sqdist<T>(Z + (int64_t)i * D, Z + (int64_t)j * D, D) * ils2;
-    const T w = kb * dcov_dr2_from_k<T>(kind, cov_from_r2<T>(kind, r2, var), r2);
+    const T w = kb * dcov_dr2_from_k<T>(kind, cov_from_r2<T>(kind, r2, var, al), r2, al);
     for (int d = 0; d < D; ++d) hs[d] += (double)(w * (Z[(int64_t)i * D + d] - Z[(int64_t)j * D + d]));
   }
   for (int d = 0; d < D; ++d) {

@@ -23,7 +23,7 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type vzero()
 // k_nm: the standalone pairwise covariance block K_nm (N x M, row-major).  HBM-write bound:
 // algorithmic bytes = N*M*s + N*D*s + M*D*s.  One 16-byte store per lane, rows contiguous.
 // =====================================================================================
-template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var);
+template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var, T alpha);
 
 // T: output / arithmetic type, TX: type of X, FAST: v_exp_f32-based exponential (roofline kernel) or exact exp
 // (the solve-precision copy of K_nm that feeds W = K_nm L^-T).  Columns M..ldo-1 of every row are written as zeros.
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
                                                   int kind, const Hyper* __restrict__ h, T* __restrict__ out, int64_t ldo) {
   using V = typename Vec16<T>::type;
   constexpr int VE = Vec16<T>::N;
-  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2, al = (T)h->alpha;
   const int vpr = (int)((ldo + VE - 1) / VE);          // 16-byte vectors per output row (ldo >= M)
   const bool aligned = (ldo % VE) == 0;
   if (vpr <= 256) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
           T r2 = 0;
 #pragma unroll
           for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[u][d] - z[e][d]; r2 += t * t; }
-          o[e] = (i0 + e < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var) : cov_from_r2<T>(kind, r2 * ils2, var)) : T(0);
+          o[e] = (i0 + e < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var, al) : cov_from_r2<T>(kind, r2 * ils2, var, al)) : T(0);
         }
         T* orow = out + row * ldo;
         if (vec_ok) { if (NT) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0)); else *reinterpret_cast<V*>(orow + i0) = o; }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
 #pragma unroll
           for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Z[(int64_t)i * D + d]; r2 += t * t; }
         }
-        o[e] = (i < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var) : cov_from_r2<T>(kind, r2 * ils2, var)) : T(0);
+        o[e] = (i < M) ? (FAST ? cov_fast<T>(kind, r2 * ils2, var, al) : cov_from_r2<T>(kind, r2 * ils2, var, al)) : T(0);
       }
       if (aligned && i0 + VE <= ldo) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0));
       else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) orow[i0 + e] = o[e];
@@ -105,9 +105,10 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
 // NT-core problems
 // =====================================================================================
 // fast exponential for the f32 GEMM operand generators (v_exp_f32); f64 keeps exp()
-template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var) { return cov_from_r2<T>(kind, r2, var); }
-template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2, float var) {
+template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var, T alpha) { return cov_from_r2<T>(kind, r2, var, alpha); }
+template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2, float var, float alpha) {
   if (kind == 0) return var * __expf(-0.5f * r2);
+  if (kind == 4) return var * __expf(-alpha * __logf(1.0f + r2 * (0.5f / alpha)));
   const float r = sqrtf(r2 + 1e-12f);
   if (kind == 3) return var * __expf(-r);
   if (kind == 2) { const float a3 = 1.7320508076f * r; return var * (1.0f + a3) * __expf(-a3); }
@@ -461,10 +462,10 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
   const T* LinvT;                  // [Mp][Mp], LinvT[i][j] = Linv[j][i]
   const T* Knm;                    // [nrows][Mp] solve-precision K_nm (same buffer the forward consumed)
   const TN* X; const T* Z; const Hyper* h;
-  double* part;                    // [gridDim.x][2]
+  double* part;                    // [gridDim.x][3]: sum Kbar*K, sum Kbar*dK/dlog(ls), sum Kbar*dK/dlog(alpha)
   double* zpart;                   // LZ: [row tiles][M][D]
   struct ACtx { const TN* p[NTCfg<T>::VPT]; };
-  struct ECtx { T s1, s2; T zs[LZ ? NTCfg<T>::NB : 1][LZ ? GDRF_DMAX : 1]; int n0; };
+  struct ECtx { T s1, s2, s3; T zs[LZ ? NTCfg<T>::NB : 1][LZ ? GDRF_DMAX : 1]; int n0; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
@@ -477,7 +478,7 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
     }
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
-    e.s1 = 0; e.s2 = 0; e.n0 = 0;
+    e.s1 = 0; e.s2 = 0; e.s3 = 0; e.n0 = 0;
     if constexpr (LZ) {
 #pragma unroll
       for (int b = 0; b < NTCfg<T>::NB; ++b)
@@ -505,7 +506,7 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
   }
   template <class Acc, int NB_>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
-    const T ils2 = (T)h->inv_ls2;
+    const T ils2 = (T)h->inv_ls2, al = (T)h->alpha;
     e.n0 = n0;
     T z[4][GDRF_DMAX];
 #pragma unroll
@@ -533,9 +534,10 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
           r2 *= ils2;
           const T kv = Knm[m * Mp + n];
           e.s1 += acc[a][b][r] * kv;
-          e.s2 += acc[a][b][r] * dcov_dlogls_from_k<T>(kind, kv, r2);
+          e.s2 += acc[a][b][r] * dcov_dlogls_from_k<T>(kind, kv, r2, al);
+          if (kind == 4) e.s3 += acc[a][b][r] * dcov_dlogalpha_from_k<T>(kind, kv, r2, al);
           if constexpr (LZ) {
-            const T w = acc[a][b][r] * dcov_dr2_from_k<T>(kind, kv, r2);
+            const T w = acc[a][b][r] * dcov_dr2_from_k<T>(kind, kv, r2, al);
 #pragma unroll
             for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) e.zs[b][d] += w * (z[b][d] - x[d]);
           }
@@ -547,7 +549,8 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
     __syncthreads();
     const double a = block_sum((double)e.s1, scratch);
     const double b = block_sum((double)e.s2, scratch);
-    if (threadIdx.x == 0) { part[2 * (int64_t)blockIdx.x] = a; part[2 * (int64_t)blockIdx.x + 1] = b; }
+    const double c3 = block_sum((double)e.s3, scratch);
+    if (threadIdx.x == 0) { part[3 * (int64_t)blockIdx.x] = a; part[3 * (int64_t)blockIdx.x + 1] = b; part[3 * (int64_t)blockIdx.x + 2] = c3; }
     if constexpr (LZ) {
       // column sums: the 4 lane groups of a wave hold 16 rows each, the two waves wr = 0, 1 the two halves of the row tile
       double* zb = reinterpret_cast<double*>(smem + 1024);       // [CW][DMAX]
@@ -814,7 +817,7 @@ __global__ void grad_small_kernel(int M, int Mp, int K, int V, const Hyper* __re
   lp = block_sum(lp, scratch);
   if (threadIdx.x == 0) {
     const double lp_phi = lp + lgam_const;
-    if (ll_const != ll_const) ll_const = red_d[6];          // NaN: the (all-reduced) data constant travels in the payload
+    if (ll_const != ll_const) ll_const = red_d[7];          // NaN: the (all-reduced) data constant travels in the payload
     const double elbo_n = red_d[0] + red_d[1] + ll_const + lp_phi;
     out_d[0] = -elbo_n / n_global;            // loss
     out_d[1] = (double)(*flag);
@@ -822,6 +825,7 @@ __global__ void grad_small_kernel(int M, int Mp, int K, int V, const Hyper* __re
     g_hyper3[0] = (T)(sc * (red_d[5] + kuu_d[1]));                              // d/d log lengthscale
     g_hyper3[1] = (T)(sc * (red_d[4] + kuu_d[0] + h->var * red_d[3]));          // d/d log variance
     g_hyper3[2] = (T)(sc * (h->noise * red_d[2]));                              // d/d log noise
+    g_hyper3[3] = (T)(sc * (red_d[6] + kuu_d[2]));                              // d/d log scale_mixture (RationalQuadratic; else 0)
   }
 }
 
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(128) void predict_rows_kernel(const TN* __restrict_
       T r2 = 0;
 #pragma unroll
       for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Zs[i * D + d]; r2 += t * t; }
-      const T kv = cov_from_r2<T>(kind, r2 * ils2, var);
+      const T kv = cov_from_r2<T>(kind, r2 * ils2, var, (T)h->alpha);
 #pragma unroll
       for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) lc[k] += kv * Cs[k * M + i];
     }

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-KERNEL_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3}
+KERNEL_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3, "rationalquadratic": 4}
 OPT_MODES = {"adam": 0, "adamw": 1, "clippedadam": 2}
 
 _WS_IDS = dict(W=0, Wbar=1, q=2, loc=3, tt=4, vbar=5, locbar=6, asum=7, Kuu=8, L=9, Linv=10, S=11, B=12, phi=13,
@@ -70,8 +70,8 @@ class Engine:
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
         zl = (C.c_int64 * 2)()
         _lib.check(self.lib.gdrf_inducing_layout(self.ctx, zl), "gdrf_inducing_layout")
-        self.layout = dict(log_lengthscale=lay[0], log_variance=lay[1], log_noise=lay[2], u_loc=lay[3], phi_unc=lay[4],
-                           u_scale_tril_unc=lay[5], inducing_unc=zl[0], total=lay[6])
+        self.layout = dict(log_lengthscale=lay[0], log_variance=lay[1], log_noise=lay[2], log_scale_mixture=3, u_loc=lay[3],
+                           phi_unc=lay[4], u_scale_tril_unc=lay[5], inducing_unc=zl[0], total=lay[6])
         # fixed_inducing_points=False of the reference: Z = sigmoid(unconstrained block), refreshed before every evaluation
         self.learn_inducing = bool(learn_inducing)
         if self.learn_inducing:
@@ -108,7 +108,7 @@ class Engine:
         buf = self.params if buf is None else buf
         o = self.layout[name]
         K, M, V = self.K, self.M, self.V
-        if name in ("log_lengthscale", "log_variance", "log_noise"):
+        if name in ("log_lengthscale", "log_variance", "log_noise", "log_scale_mixture"):
             return buf[o:o + 1].view(())
         if name == "u_loc":
             return buf[o:o + K * M].view(K, M)
@@ -121,6 +121,13 @@ class Engine:
         raise KeyError(name)
 
     PARAM_NAMES = ("log_lengthscale", "log_variance", "log_noise", "u_loc", "phi_unc", "u_scale_tril_unc")
+
+    @property
+    def param_names(self):
+        """PARAM_NAMES plus the blocks only some configurations learn (RationalQuadratic's scale_mixture, inducing inputs)."""
+        extra = (("log_scale_mixture",) if self.kernel == "rationalquadratic" else ()) + \
+                (("inducing_unc",) if self.learn_inducing else ())
+        return self.PARAM_NAMES + extra
 
     def named_views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         return {n: self.view(n, buf) for n in self.PARAM_NAMES}
@@ -330,7 +337,7 @@ class Engine:
         if self._distributed():
             import torch.distributed as dist
             pg = None if isinstance(self.pg, str) else self.pg
-            self.red_d[6] = llc                      # the data constant is a sum over observations too
+            self.red_d[7] = llc                      # the data constant is a sum over observations too
             dist.all_reduce(self.red_T, group=pg)    # RCCL over xGMI (backend "nccl" on ROCm)
             dist.all_reduce(self.red_d, group=pg)
             llc = None
@@ -347,7 +354,7 @@ class Engine:
 
     def _finish(self, n_global: float, ll_const: Optional[float]):
         s = _stream_ptr(self.device)
-        if ll_const is None:                         # the reduced copy travels in red_d[6]; the kernel reads it there (no host sync)
+        if ll_const is None:                         # the reduced copy travels in red_d[7]; the kernel reads it there (no host sync)
             ll_const = float("nan")
         _lib.check(self.lib.gdrf_step_finish(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.red_T.data_ptr(),
                                              self.red_d.data_ptr(), n_global, ll_const, self.grads.data_ptr(),

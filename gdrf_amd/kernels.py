@@ -50,10 +50,17 @@ class Exponential(Kernel):
 
 
 class RationalQuadratic(Kernel):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("RationalQuadratic carries a third learnable hyper-parameter (scale_mixture) that the flat "
-                                  "parameter layout of this build does not hold yet (SURVEY.md 8(f) item 4); RBF, Matern52, "
-                                  "Matern32 and Exponential are in")
+    """variance * (1 + r2 / (2 scale_mixture))^(-scale_mixture); scale_mixture is a third positive, learnable
+    hyper-parameter (pyro.contrib.gp.kernels.RationalQuadratic(input_dim, variance, lengthscale, scale_mixture))."""
+    name = "rationalquadratic"
+    kernel_id = 4
+
+    def __init__(self, input_dim: int, variance=None, lengthscale=None, scale_mixture=None, active_dims=None):
+        super().__init__(input_dim, variance=variance, lengthscale=lengthscale, active_dims=active_dims)
+        self.scale_mixture = torch.as_tensor(1.0 if scale_mixture is None else scale_mixture,
+                                             dtype=torch.float64).detach().cpu().reshape(())
+        if not self.scale_mixture > 0:
+            raise ValueError("scale_mixture must be positive")
 
 
 KERNEL_DICT = {"rbf": RBF, "matern32": Matern32, "matern52": Matern52, "exponential": Exponential,

@@ -25,6 +25,7 @@ _PARAM_KEYS = {  # state_dict names follow pyro's "<name>_unconstrained" convent
     "phi_unc": "_word_topic_matrix_map_unconstrained",
     "u_scale_tril_unc": "u_scale_tril_unconstrained",
     "inducing_unc": "_inducing_points_unconstrained",          # only when fixed_inducing_points=False
+    "log_scale_mixture": "_kernel.scale_mixture_unconstrained",  # only with the RationalQuadratic kernel
 }
 
 
@@ -176,6 +177,8 @@ class SparseMultinomialGDRF:
             eng.view("log_lengthscale").fill_(float(self._kernel.lengthscale.log()))
             eng.view("log_variance").fill_(float(self._kernel.variance.log()))
             eng.view("log_noise").fill_(float(torch.tensor(self._init_noise, dtype=torch.float64).log()))
+            if self._kernel.name == "rationalquadratic":
+                eng.view("log_scale_mixture").fill_(float(self._kernel.scale_mixture.log()))
             eng.view("u_loc").zero_()
             ret = torch.softmax(self._dirichlet_param, dim=-2)           # over K (abstract_gdrf.py:68-69)
             if self._randomize_wt:
@@ -303,13 +306,10 @@ class SparseMultinomialGDRF:
         return {_PARAM_KEYS[n]: self._engine.view(n).detach().clone() for n in self._param_names()}
 
     def _param_names(self):
-        names = tuple(self._engine.PARAM_NAMES)
-        return names if self._fixed_inducing_points else names + ("inducing_unc",)
+        return tuple(self._engine.param_names)
 
     def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True):
-        v = dict(self._engine.named_views())
-        if not self._fixed_inducing_points:
-            v["inducing_unc"] = self._engine.view("inducing_unc")
+        v = {n: self._engine.view(n) for n in self._param_names()}
         missing = []
         for n in self._param_names():
             key = _PARAM_KEYS[n]
@@ -327,8 +327,7 @@ class SparseMultinomialGDRF:
         return missing
 
     def parameters(self):
-        ps = list(self._engine.named_views().values())
-        return ps if self._fixed_inducing_points else ps + [self._engine.view("inducing_unc")]
+        return [self._engine.view(n) for n in self._param_names()]
 
     def float(self):
         return self

@@ -26,7 +26,7 @@ extern "C" {
 typedef struct gdrf_ctx gdrf_ctx;
 
 enum { GDRF_F32 = 0, GDRF_F64 = 1, GDRF_F32_PURE = 2 };
-enum { GDRF_RBF = 0, GDRF_MATERN52 = 1, GDRF_MATERN32 = 2, GDRF_EXPONENTIAL = 3 };
+enum { GDRF_RBF = 0, GDRF_MATERN52 = 1, GDRF_MATERN32 = 2, GDRF_EXPONENTIAL = 3, GDRF_RATIONALQUADRATIC = 4 };
 enum { GDRF_ADAM = 0, GDRF_ADAMW = 1, GDRF_CLIPPED_ADAM = 2 };
 enum { GDRF_PRED_LOC = 0, GDRF_PRED_TOPIC_PROBS = 1, GDRF_PRED_WORD_PROBS = 2, GDRF_PRED_PERPLEXITY = 3 };
 
@@ -64,7 +64,10 @@ void gdrf_ctx_destroy(gdrf_ctx* ctx);
 
 /* Flat unconstrained-parameter vector (the PyroParam storage of gdrf/models/sparse_gdrf.py:96-122
  * and the pyro kernel's lengthscale/variance): out = {off_log_lengthscale, off_log_variance,
- * off_log_noise, off_u_loc (K*M), off_phi_unc (K*V), off_u_scale_tril_unc (K*M*M), total}. */
+ * off_log_noise, off_u_loc (K*M), off_phi_unc (K*V), off_u_scale_tril_unc (K*M*M), total}.  Element 3 of the vector
+ * (between log_noise and u_loc) is log(scale_mixture) of the RationalQuadratic kernel (pyro 1.8.0
+ * kernels.isotropic.RationalQuadratic: variance * (1 + r2 / (2 scale_mixture))^(-scale_mixture)); the other kernels
+ * ignore it and its gradient is 0. */
 int gdrf_param_layout(const gdrf_ctx* ctx, int64_t out[7]);
 /* Per-step all-reduce payload: out = {off_ubar, off_phibar, off_A, off_GT, total_T, total_d}. */
 int gdrf_red_layout(const gdrf_ctx* ctx, int64_t out[6]);
@@ -108,7 +111,7 @@ int gdrf_step_local(gdrf_ctx* ctx, const void* X_dev, const int32_t* ws_dev, con
 /* Replicated epilogue: Cholesky / kernel hyper-parameter backward, constraint Jacobians, Dirichlet
  * term, loss.  grads (same layout as params) = d loss / d unconstrained.  out_d (8 doubles) =
  * {loss, cholesky_failed, site_sum, loglik_sum, log_prior_phi, ...}.  ll_const = the data-only constant of the
- * Multinomial log-likelihood (gdrf_ll_const, summed over ranks); pass NaN to take it from red_d[6] on the device. */
+ * Multinomial log-likelihood (gdrf_ll_const, summed over ranks); pass NaN to take it from red_d[7] on the device. */
 int gdrf_step_finish(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const void* red_T_dev,
                      const double* red_d_dev, double n_global, double ll_const, void* grads_dev, double* out_d_dev,
                      void* stream);

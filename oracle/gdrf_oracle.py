@@ -57,10 +57,14 @@ def square_scaled_dist(X: torch.Tensor, Z: torch.Tensor, lengthscale: torch.Tens
     return r2.clamp(min=0)
 
 
-def kernel_matrix(kind: str, X: torch.Tensor, Z: torch.Tensor, lengthscale, variance) -> torch.Tensor:
+def kernel_matrix(kind: str, X: torch.Tensor, Z: torch.Tensor, lengthscale, variance, scale_mixture=None) -> torch.Tensor:
     r2 = square_scaled_dist(X, Z, lengthscale)
     if kind == "rbf":
         return variance * torch.exp(-0.5 * r2)
+    if kind == "rationalquadratic":
+        # pyro 1.8.0 kernels.isotropic.RationalQuadratic.forward (third-party, not in the tree; published formula):
+        # variance * (1 + (0.5 / scale_mixture) * r2).pow(-scale_mixture), scale_mixture a positive PyroParam, default 1
+        return variance * (1 + (0.5 / scale_mixture) * r2).pow(-scale_mixture)
     r = (r2 + 1e-12).sqrt()
     if kind == "matern52":
         s5r = SQRT5 * r
@@ -107,11 +111,11 @@ def jitter_total(jitter: float, level: int) -> float:
 # --------------------------------------------------------------------------
 # pyro.contrib.gp.util.conditional, full_cov=False, whiten=True  
 # --------------------------------------------------------------------------
-def conditional(kind, Xnew, Z, lengthscale, variance, u_loc, u_scale_tril, Lff):
+def conditional(kind, Xnew, Z, lengthscale, variance, u_loc, u_scale_tril, Lff, scale_mixture=None):
     M = Z.size(0)
     K = u_loc.size(0)
     N = Xnew.size(0)
-    Kfs = kernel_matrix(kind, Z, Xnew, lengthscale, variance)            # (M,N)
+    Kfs = kernel_matrix(kind, Z, Xnew, lengthscale, variance, scale_mixture)            # (M,N)
     v_2D = u_loc.reshape(-1, M).t()                                      # (M,K)
     S_2D = u_scale_tril.reshape(-1, M, M).permute(1, 2, 0).reshape(M, -1)  # (M, M*K): col = j*K + k
     W = torch.linalg.solve_triangular(Lff, Kfs, upper=False).t()         # (N,M)
@@ -160,7 +164,7 @@ class RefShapedGDRF:
     def __init__(self, xs, ws, *, kind="rbf", K=3, n_points=(8, 4), lengthscale=0.1, variance=25.0,
                  dirichlet_param=0.01, jitter=1e-8, maxjitter=15, noise=1.0, dtype=torch.float64,
                  Z: Optional[torch.Tensor] = None, optimizer="adam", lr=1e-3,
-                 force_jitter_level: Optional[int] = None, learn_inducing: bool = False):
+                 force_jitter_level: Optional[int] = None, learn_inducing: bool = False, scale_mixture: float = 1.0):
         self.dtype = dtype
         self.kind = kind
         self.K = K
@@ -177,7 +181,8 @@ class RefShapedGDRF:
         # unconstrained parameters (PyroParam storage)
         ls = torch.tensor(float(lengthscale), dtype=dtype)
         var = torch.tensor(float(variance), dtype=dtype)
-        Kuu = kernel_matrix(kind, self.Z, self.Z, ls, var)
+        sm = torch.tensor(float(scale_mixture), dtype=dtype)
+        Kuu = kernel_matrix(kind, self.Z, self.Z, ls, var, sm)
         L0, self.init_jitter_level = jittercholesky(Kuu, self.M, jitter, maxjitter,
                                                     force_level=force_jitter_level)
         wt = torch.softmax(self.alpha, dim=-2)           # abstract_gdrf.py:68-69 (over K)
@@ -189,6 +194,8 @@ class RefShapedGDRF:
             "log_noise": torch.tensor(float(noise), dtype=dtype).log().clone(),
             "phi_unc": wt.log().clone(),                  # simplex transform inverse = log
         }
+        if kind == "rationalquadratic":
+            self.params["log_scale_mixture"] = sm.log().clone()          # positive constraint -> exp
         self.learn_inducing = bool(learn_inducing)
         if self.learn_inducing:
             # sparse_gdrf.py:79-88: PyroParam(scaled points, constraint=stack([interval(0, 1)] * D)); the stored value is
@@ -218,11 +225,12 @@ class RefShapedGDRF:
             u_scale_tril=transform_to(constraints.lower_cholesky)(p["u_scale_tril_unc"]),
             noise=p["log_noise"].exp(),
             phi=torch.softmax(p["phi_unc"], dim=-1),
+            scale_mixture=p["log_scale_mixture"].exp() if "log_scale_mixture" in p else None,
         )
 
     def _luu(self, c):
         Zc = self.inducing()
-        Kuu = kernel_matrix(self.kind, Zc, Zc, c["lengthscale"], c["variance"]).contiguous()
+        Kuu = kernel_matrix(self.kind, Zc, Zc, c["lengthscale"], c["variance"], c["scale_mixture"]).contiguous()
         L, lvl = jittercholesky(Kuu, self.M, self.jitter, self.maxjitter, force_level=self.force_jitter_level)
         self.last_jitter_level = lvl
         return L
@@ -237,14 +245,14 @@ class RefShapedGDRF:
         # guide: sparse_gdrf.py:375-409
         Luu = self._luu(c)
         f_loc, f_var = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
-                                   c["u_loc"], c["u_scale_tril"], Luu)
+                                   c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"])
         q_mu = Normal(f_loc, f_var)                       # Q1: variance passed as scale
         mu = f_loc + f_var * eps                          # rsample with injected eps
         lq_mu = q_mu.log_prob(mu).sum()
         # model (replayed with mu, phi): sparse_gdrf.py:323-373
         Luu2 = self._luu(c)
         f_loc2, f_var2 = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
-                                     c["u_loc"], c["u_scale_tril"], Luu2)
+                                     c["u_loc"], c["u_scale_tril"], Luu2, c["scale_mixture"])
         lp_mu = Normal(f_loc2, f_var2 + c["noise"]).log_prob(mu).sum()
         lp_phi = Dirichlet(self.alpha).log_prob(c["phi"]).sum()
         topic_probs = torch.softmax(mu, -2).transpose(-2, -1)
@@ -296,7 +304,7 @@ class RefShapedGDRF:
         c = self.constrained()
         Luu = self._luu(c)
         f_loc, _ = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
-                               c["u_loc"], c["u_scale_tril"], Luu)
+                               c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"])
         return f_loc
 
     def topic_probs(self, xs=None):

@@ -10,7 +10,7 @@ NAME_MAP = dict(log_lengthscale="log_lengthscale", log_variance="log_variance", 
 
 def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.float64, seed=1, jitter=1e-6,
                 perturb=True, one_d=False, optimizer="adam", lr=1e-3, force_jitter_level=None, lengthscale=0.1,
-                learn_inducing=False, random_inducing=False):
+                learn_inducing=False, random_inducing=False, scale_mixture=1.0):
     xs, ws, _ = synth_circles(W, H, V, K, seed=seed, one_d=one_d)
     g = torch.Generator().manual_seed(seed + 100)
     Z = None
@@ -18,7 +18,8 @@ def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.f
         M = int(np.prod(n_points)) if not one_d else int(n_points[0])
         Z = 0.05 + 0.9 * torch.rand(M, 1 if one_d else 2, generator=g, dtype=torch.float64)
     m = RefShapedGDRF(xs, ws, kind=kind, K=K, n_points=n_points, dtype=dtype, jitter=jitter, optimizer=optimizer, lr=lr,
-                      force_jitter_level=force_jitter_level, lengthscale=lengthscale, Z=Z, learn_inducing=learn_inducing)
+                      force_jitter_level=force_jitter_level, lengthscale=lengthscale, Z=Z, learn_inducing=learn_inducing,
+                      scale_mixture=scale_mixture)
     if perturb:
         with torch.no_grad():
             m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64).to(dtype))
@@ -47,8 +48,9 @@ def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=Fal
 def load_params(eng, m):
     for name in eng.PARAM_NAMES:
         eng.view(name).copy_(m.params[name].detach().to(eng.dtype))
-    if getattr(m, "learn_inducing", False):
-        eng.view("inducing_unc").copy_(m.params["inducing_unc"].detach().to(eng.dtype))
+    for name in ("inducing_unc", "log_scale_mixture"):          # blocks only some configurations carry
+        if name in m.params:
+            eng.view(name).copy_(m.params[name].detach().to(eng.dtype))
 
 
 def dev(t, eng, dtype=None):

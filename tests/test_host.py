@@ -43,8 +43,10 @@ def test_kernel_registry_and_arguments():
     assert isinstance(k, RBF) and k.to("cuda:0") is k and abs(float(k.lengthscale) - 0.1) < 1e-7
     assert isinstance(KERNEL_DICT["matern52"](input_dim=1), Matern52)
     assert KERNEL_DICT["matern32"](input_dim=1).kernel_id == 2 and KERNEL_DICT["exponential"](input_dim=1).kernel_id == 3
-    with pytest.raises(NotImplementedError):
-        KERNEL_DICT["rationalquadratic"](input_dim=1)
+    rq = KERNEL_DICT["rationalquadratic"](input_dim=1, scale_mixture=torch.tensor(2.0))
+    assert rq.kernel_id == 4 and float(rq.scale_mixture) == 2.0 and float(KERNEL_DICT["rationalquadratic"](input_dim=1).scale_mixture) == 1.0
+    with pytest.raises(ValueError):
+        KERNEL_DICT["rationalquadratic"](input_dim=1, scale_mixture=torch.tensor(0.0))
     with pytest.raises(ValueError):
         RBF(2, lengthscale=torch.tensor(-1.0))
 
