@@ -261,7 +261,7 @@ class Engine:
         raise RuntimeError("reached max jitter, covariance is unstable")
 
     def loss_and_grads(self, xs, ws, eps, n_global: Optional[int] = None, ll_const: Optional[float] = None,
-                       force_level: Optional[int] = None):
+                       force_level: Optional[int] = None, renyi_alpha: Optional[float] = None):
         """One ELBO evaluation + backward.  Leaves d loss/d unconstrained in self.grads (device) and
         returns nothing host-side; call read_out() for the loss."""
         self._chk_rows(xs, ws)
@@ -278,7 +278,7 @@ class Engine:
         guess = self._guess_level if (force_level is None and self.speculate) else None
         if guess is None:
             self.factorize(force_level)
-            self._local_and_finish(xs, ws, eps, P, n, ng, llc, s)
+            self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
         else:
             # Speculate on the previous step's jitter level: the solve-precision factorisation and the whole step go onto
             # the main stream at once, the array-precision probe (which decides the level, as the reference's fp32
@@ -292,7 +292,7 @@ class Engine:
                        "gdrf_factorize")
             fact_done = torch.cuda.Event()
             fact_done.record(main)
-            self._local_and_finish(xs, ws, eps, P, n, ng, llc, s)
+            self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
             ps = self._probe_stream.cuda_stream
             level = self._probe_level(ps)
             failed = C.c_int()
@@ -303,7 +303,7 @@ class Engine:
             else:
                 torch.cuda.synchronize(self.device)
                 self.factorize(None)
-                self._local_and_finish(xs, ws, eps, P, n, ng, llc, s)
+                self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
         self._guess_level = self.last_jitter_level if force_level is None else None
 
     def _probe_level(self, stream_ptr: int) -> int:
@@ -320,23 +320,43 @@ class Engine:
             level += nlev
         raise RuntimeError("reached max jitter, covariance is unstable")
 
-    def _local_and_finish(self, xs, ws, eps, P, n, ng, llc, s):
+    def _local_and_finish(self, xs, ws, eps, P, n, ng, llc, s, renyi_alpha=None):
+        """The N-side kernels for every particle, the particle combination, the all-reduce and the replicated epilogue.
+        Trace_ELBO averages the P payloads (every entry is linear in the per-particle sums).  RenyiELBO(alpha) weights them
+        with w_p = softmax_p((1 - alpha) e_p), e_p = the particle-varying part of the scaled ELBO (site + likelihood sums
+        over ALL ranks; the terms shared by the particles factor out of the logsumexp), and reports
+        -(logsumexp((1 - alpha) e_p) - log P) / (1 - alpha) through the payload's site slot.  All on the device."""
+        dist_on = self._distributed()
+        if dist_on:
+            import torch.distributed as dist
+            pg = None if isinstance(self.pg, str) else self.pg
+        if renyi_alpha is not None and float(renyi_alpha) == 1.0:
+            raise ValueError("RenyiELBO: alpha must differ from 1")
+        Ts, ds = [], []
         for p in range(P):
             _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n, self.Z.data_ptr(),
                                                 self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
                        "gdrf_step_local")
-            if P > 1:                             # every payload entry is linear in the per-particle sums
-                if p == 0:
-                    acc_T, acc_d = self.red_T.clone(), self.red_d.clone()
-                else:
-                    acc_T += self.red_T
-                    acc_d += self.red_d
-        if P > 1:
-            self.red_T.copy_(acc_T / P)
-            self.red_d.copy_(acc_d / P)
-        if self._distributed():
-            import torch.distributed as dist
-            pg = None if isinstance(self.pg, str) else self.pg
+            if P > 1 or renyi_alpha is not None:
+                Ts.append(self.red_T.clone()); ds.append(self.red_d.clone())
+        if renyi_alpha is not None:
+            T_all, d_all = torch.stack(Ts), torch.stack(ds)
+            e = d_all[:, 0] + d_all[:, 1]                         # this rank's site + likelihood sums per particle
+            if dist_on:
+                dist.all_reduce(e, group=pg)
+            logw = (1.0 - float(renyi_alpha)) * e / ng
+            w = torch.softmax(logw, 0)
+            self.red_T.copy_((w.to(T_all.dtype)[:, None] * T_all).sum(0))
+            self.red_d.copy_((w[:, None] * d_all).sum(0))
+            bound = (torch.logsumexp(logw, 0) - math.log(P)) / (1.0 - float(renyi_alpha))      # scaled by 1/N already
+            # step_finish forms loss = -(red_d[0] + red_d[1] + constants) / N from the REDUCED payload: one rank carries it
+            first = (not dist_on) or dist.get_rank(pg) == 0
+            self.red_d[0] = bound * ng if first else 0.0
+            self.red_d[1] = 0.0
+        elif P > 1:
+            self.red_T.copy_(torch.stack(Ts).mean(0))
+            self.red_d.copy_(torch.stack(ds).mean(0))
+        if dist_on:
             self.red_d[7] = llc                      # the data constant is a sum over observations too
             dist.all_reduce(self.red_T, group=pg)    # RCCL over xGMI (backend "nccl" on ROCm)
             dist.all_reduce(self.red_d, group=pg)

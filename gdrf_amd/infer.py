@@ -33,8 +33,16 @@ class TraceGraph_ELBO(_ELBO):  # noqa: N801
 
 
 class RenyiELBO(_ELBO):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("RenyiELBO is a different estimator (num_particles > 1), outside this build's hot path")
+    """pyro.infer.RenyiELBO(alpha=0, num_particles=2, ...) (gdrf/train_script.py:88-92,330-335): the Renyi alpha-divergence
+    bound  -(logsumexp_p((1 - alpha) elbo_p) - log P) / (1 - alpha); alpha = 0 is the importance-weighted (IWAE) bound.
+    The particles' payloads are combined with their normalised importance weights on the device (Engine._local_and_finish)."""
+
+    def __init__(self, alpha: float = 0.0, num_particles: int = 2, max_plate_nesting: int = float("inf"),
+                 vectorize_particles: bool = False, **kwargs):
+        if float(alpha) == 1.0:
+            raise ValueError("The order alpha should not be equal to 1. Please use Trace_ELBO class for the case alpha = 1.")
+        super().__init__(num_particles=num_particles, max_plate_nesting=max_plate_nesting, vectorize_particles=vectorize_particles)
+        self.alpha = float(alpha)
 
 
 OBJECTIVE_DICT = {"elbo": Trace_ELBO, "graphelbo": TraceGraph_ELBO, "renyielbo": RenyiELBO}
@@ -61,7 +69,7 @@ class SVI:
         if abs(m_scale - g_scale) > 1e-15 * max(m_scale, g_scale):
             raise ValueError("model and guide carry different poutine.scale factors")
         if not isinstance(loss, _ELBO):
-            raise TypeError("loss must be gdrf_amd.infer.Trace_ELBO or TraceGraph_ELBO")
+            raise TypeError("loss must be gdrf_amd.infer.Trace_ELBO, TraceGraph_ELBO or RenyiELBO")
         self.gdrf = m_owner
         self.scale = m_scale
         self.optim = optim
@@ -81,7 +89,7 @@ class SVI:
         self.optim._bind(eng)
         n = xs_s.shape[0]
         eps = self._eps(eng, eps, n)
-        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale)
+        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale, renyi_alpha=getattr(self.loss, "alpha", None))
         self.optim._step()
         out = eng.read_out()
         self.steps_taken += 1
@@ -96,7 +104,8 @@ class SVI:
         xs_s, ws_d = model._prepare_inputs(xs, ws)
         eng = model._engine_for(xs_s.shape[0])
         n = xs_s.shape[0]
-        eng.loss_and_grads(xs_s, ws_d, self._eps(eng, eps, n), n_global=1.0 / self.scale)
+        eng.loss_and_grads(xs_s, ws_d, self._eps(eng, eps, n), n_global=1.0 / self.scale,
+                           renyi_alpha=getattr(self.loss, "alpha", None))
         return float(eng.read_out()["loss"])
 
     def _eps(self, eng, eps, n):

@@ -263,10 +263,19 @@ class RefShapedGDRF:
                                ll=float(ll.detach()))
         return -elbo
 
-    def loss_and_grads(self, eps, **kw) -> Tuple[float, Dict[str, torch.Tensor]]:
+    def renyi_loss(self, eps: torch.Tensor, alpha: float = 0.0, **kw) -> torch.Tensor:
+        """pyro.infer.RenyiELBO(alpha, num_particles=P) (pyro-ppl 1.8.0, third-party; published estimator, Li & Turner 2016):
+        with the scaled per-particle ELBOs e_p,  loss = -(logsumexp((1 - alpha) e_p) - log P) / (1 - alpha).  All sites are
+        reparameterised, so pyro's surrogate gradient (normalised detached weights times grad e_p) is the gradient of this."""
+        eps = torch.as_tensor(eps)
+        assert eps.dim() == 3 and alpha != 1.0
+        e = torch.stack([-self.loss(eps[p], **kw) for p in range(eps.shape[0])])
+        return -(torch.logsumexp((1.0 - alpha) * e, 0) - math.log(eps.shape[0])) / (1.0 - alpha)
+
+    def loss_and_grads(self, eps, renyi_alpha: Optional[float] = None, **kw) -> Tuple[float, Dict[str, torch.Tensor]]:
         for p in self.params.values():
             p.grad = None
-        loss = self.loss(eps, **kw)
+        loss = self.loss(eps, **kw) if renyi_alpha is None else self.renyi_loss(eps, renyi_alpha, **kw)
         loss.backward()
         return float(loss.detach()), {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
                              for k, p in self.params.items()}

@@ -391,3 +391,21 @@ def test_rationalquadratic_kernel_matches_autograd(learn_z):
     e32.loss_and_grads(dev(m.xs, e32), dev(m.ws, e32, torch.int32), dev(eps, e32))
     g32 = float(e32.view("log_scale_mixture", e32.grads).cpu())
     assert abs(g32 - float(grads["log_scale_mixture"])) < 5e-3 * abs(float(grads["log_scale_mixture"])) + 1e-9
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.5, 2.0])
+def test_renyi_elbo_matches_the_oracle(alpha):
+    """RenyiELBO(alpha, num_particles=3): importance-weighted combination of the particles' payloads on the device against
+    autograd through -(logsumexp((1 - alpha) elbo_p) - log P) / (1 - alpha)."""
+    m, _ = make_oracle(dtype=torch.float64, jitter=1e-6)
+    eng = engine_from_oracle(m)
+    g = torch.Generator().manual_seed(11)
+    eps = 3.0 * torch.randn(3, m.K, m.N, generator=g, dtype=torch.float64)       # wide draws: clearly unequal weights
+    loss, grads = m.loss_and_grads(eps, renyi_alpha=alpha)
+    single = [m.loss_and_grads(eps[p])[0] for p in range(3)]
+    assert max(single) - min(single) > 1e-3 * abs(loss)
+    eng.loss_and_grads(dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), renyi_alpha=alpha)
+    out = eng.read_out()
+    assert abs(out["loss"] - loss) < LOSS_TOL_VS_TORCH * abs(loss)
+    for name in eng.PARAM_NAMES:
+        assert relerr(eng.view(name, eng.grads).cpu().numpy(), grads[name].numpy()) < 1e-7, name

@@ -71,8 +71,10 @@ def test_objectives_and_scale_wrapper():
     assert OBJECTIVE_DICT["elbo"](num_particles=4).num_particles == 4
     with pytest.raises(ValueError):
         OBJECTIVE_DICT["elbo"](num_particles=0)
-    with pytest.raises(NotImplementedError):
-        OBJECTIVE_DICT["renyielbo"](alpha=2.0)
+    r = OBJECTIVE_DICT["renyielbo"](max_plate_nesting=1, vectorize_particles=True, num_particles=3, alpha=2.0)
+    assert r.alpha == 2.0 and r.num_particles == 3 and OBJECTIVE_DICT["renyielbo"]().num_particles == 2
+    with pytest.raises(ValueError):
+        OBJECTIVE_DICT["renyielbo"](alpha=1.0)
     sc = poutine.scale(scale=0.25)
 
     def f():
