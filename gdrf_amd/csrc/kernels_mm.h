@@ -58,6 +58,15 @@ __global__ void kuu_kernel(const T* __restrict__ Z, int M, int Mp, int D, int ki
 // blockIdx.x selects an independent problem: matrix A + blockIdx.x * batch_stride, flag[blockIdx.x] (the jitter
 // probe factorises the same K_uu with several cumulative jitters in one launch).
 #define CHOL_PC 256
+__device__ __forceinline__ float chol_readlane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double chol_readlane(double v, int lane) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
 template <typename T>
 __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, int ld, int* __restrict__ flag, int64_t batch_stride) {
   using MM = Mfma<T>;
@@ -73,8 +82,14 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
   T* Scol = reinterpret_cast<T*>(Sb + 32);   // [32]
   A += (int64_t)blockIdx.x * batch_stride;
   flag += blockIdx.x;
-  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+#ifdef GDRF_CHOL_PROF
+  unsigned long long tph[4] = {0, 0, 0, 0}, t0 = __builtin_readcyclecounter();
+#define CHOL_TICK(i) { const unsigned long long t1 = __builtin_readcyclecounter(); tph[i] += t1 - t0; t0 = t1; }
+#else
+#define CHOL_TICK(i)
+#endif
   for (int c0 = 0; c0 < M; c0 += 32) {
     // ---- (a) panel update.  The panel rows are staged in column chunks of CHOL_PC; a wave keeps the accumulators
     //      of up to NS of its strips across the chunks (more strips: another pass over the chunks).
@@ -126,7 +141,8 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
       }
       __syncthreads();
     }
-    // ---- (b) factor the 32x32 diagonal block: one wave, one row per lane
+    CHOL_TICK(0)
+    // ---- (b) factor the 32x32 diagonal block: one wave, one row per lane, rows in registers
     if (wave == 0) {
       const int l = lane & 31;                 // lanes 32..63 mirror lanes 0..31 (same values, same writes)
       T x[32];
@@ -137,19 +153,41 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
       }
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
-        T d = __shfl(x[j], j, 64);
+        T d = chol_readlane(x[j], j);
         if (!(d > T(0))) { if (lane == 0 && c0 + j < M) *flag = 1; d = T(1); }
-        const T piv = t_sqrt<T>(d);
-        x[j] = (l == j) ? piv : ((l > j) ? x[j] / piv : T(0));
-        Scol[l] = x[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = j + 1; c < 32; ++c) {
-          const T lcj = Scol[c];
-          if (l >= c) x[c] -= x[j] * lcj;
+        T piv, rp;
+        if constexpr (sizeof(T) == 8) {
+          // sqrt and reciprocal from ONE v_rsq_f64 seed and Newton steps (the library sqrt + divide pair is ~45 dependent
+          // instructions on this serial chain): y -> y (1.5 - 0.5 d y^2) twice, then piv = d y with one correction
+          double y = __builtin_amdgcn_rsq(d);
+          y = y * (1.5 - 0.5 * d * y * y);
+          y = y * (1.5 - 0.5 * d * y * y);
+          double p0 = d * y;
+          p0 = p0 + 0.5 * y * (d - p0 * p0);
+          piv = p0; rp = y + y * (1.0 - p0 * y);
+        } else {
+          piv = t_sqrt<T>(d); rp = T(1) / piv;
         }
-        __builtin_amdgcn_wave_barrier();
+        x[j] = (l == j) ? piv : ((l > j) ? x[j] * rp : T(0));
+        if constexpr (sizeof(T) == 4) {
+          // f32: the column reaches the other lanes through v_readlane (compile-time lane index, no LDS round trip)
+#pragma unroll
+          for (int c = j + 1; c < 32; ++c) {
+            const T lcj = chol_readlane(x[j], c);
+            if (l >= c) x[c] -= x[j] * lcj;
+          }
+        } else {
+          // f64: two readlanes per value plus their hazards measured slower than a broadcast through LDS
+          Scol[l] = x[j];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int c = j + 1; c < 32; ++c) {
+            const T lcj = Scol[c];
+            if (l >= c) x[c] -= x[j] * lcj;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
       }
       if (lane < 32) {
 #pragma unroll
@@ -157,34 +195,41 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
           Sa[l][j] = x[j];
           if (c0 + l < M && c0 + j < M) A[(int64_t)(c0 + l) * ld + c0 + j] = x[j];
         }
-      }
-    }
-    __syncthreads();
-    // ---- (c) rows below the block: X = U Ld^{-T}.  Ld^{-1} by forward substitution (one column per thread) into Sb
-    Sb[ty][tx] = 0;
-    __syncthreads();
-    if (tid < 32) {
-      const int c = tid;
-      Sb[c][c] = T(1) / Sa[c][c];
-      for (int r = c + 1; r < 32; ++r) {
-        T s = 0;
-        for (int q = c; q < r; ++q) s += Sa[r][q] * Sb[q][c];
-        Sb[r][c] = -s / Sa[r][r];
-      }
-    }
-    __syncthreads();
-    for (int i0 = c0 + 32; i0 < M; i0 += 32) {
-      // reuse Sa for the panel rows (the factored block already went back to global memory)
-      __syncthreads();
-      Sa[ty][tx] = (i0 + ty < M) ? A[(int64_t)(i0 + ty) * ld + c0 + tx] : T(0);
-      __syncthreads();
-      T o = 0;
+        T dg = T(1);
 #pragma unroll
-      for (int q = 0; q < 32; ++q) o += Sa[ty][q] * Sb[tx][q];     // x_j = sum_q a_q Linv[j][q]
-      if (i0 + ty < M) A[(int64_t)(i0 + ty) * ld + c0 + tx] = o;
+        for (int j = 0; j < 32; ++j) if (l == j) dg = x[j];
+        Scol[l] = T(1) / dg;                   // reciprocal pivots for the rows below
+      }
     }
     __syncthreads();
+    CHOL_TICK(1)
+    CHOL_TICK(2)
+    // ---- (c) rows below the block: x Ld^T = u, one row per thread by forward substitution in registers; the factored block
+    //      (Sa) and the reciprocal pivots (Scol) are broadcast reads from LDS
+    for (int i0 = c0 + 32; i0 < M; i0 += 1024) {
+      const int row = i0 + tid;
+      if (row < M) {
+        T a[32];
+        T* arow = A + (int64_t)row * ld + c0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a[j] = arow[j];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          T sacc = a[j];
+#pragma unroll
+          for (int q = 0; q < j; ++q) sacc -= a[q] * Sa[j][q];
+          a[j] = sacc * Scol[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (c0 + j < M) arow[j] = a[j];
+      }
+    }
+    __syncthreads();
+    CHOL_TICK(3)
   }
+#ifdef GDRF_CHOL_PROF
+  if (tid == 0 && blockIdx.x == 0) printf("chol<%d> cycles: update %llu  diag %llu  inverse %llu  apply %llu\n", (int)sizeof(T), tph[0], tph[1], tph[2], tph[3]);
+#endif
 }
 
 // dynamic LDS bytes of chol_kernel<T>
