@@ -149,7 +149,8 @@ def main():
     model = SparseMultinomialGDRF(
         xs=xs, ws=ws, world=[(0.0, 1.0)] * D, kernel=kernel, num_observation_categories=args.vocab, device=str(device),
         num_topic_categories=args.topics, dirichlet_param=0.01, n_points=list(args.n_points), fixed_inducing_points=True,
-        inducing_init="grid", maxjitter=15, jitter=args.jitter, randomize_wt_matrix=False, dtype=dtype, seed=args.seed)
+        inducing_init="grid", maxjitter=15, jitter=args.jitter, randomize_wt_matrix=False, dtype=dtype, seed=args.seed,
+        mfma_mode=args.mfma_mode)
     M = model.M
     optimizer = Adam({"lr": 1e-3})
     objective = Trace_ELBO(max_plate_nesting=1, vectorize_particles=True, num_particles=1)
