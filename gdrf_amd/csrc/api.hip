@@ -66,6 +66,8 @@ struct gdrf_ctx {
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
   hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join, ev_fact0, ev_fact;
   int fact_pending;           // a factorisation has been queued on the side stream: consumers wait for ev_fact
+  int unwhitened;             // whiten = False: u' = L^-1 u, S' = L^-1 S (solve-precision scratch below, allocated on demand)
+  void *uS, *uSb, *uSc, *uU, *uUb, *Uw;
   int learn_z; double* zpart; // learnable inducing inputs: per-row-tile partial sums [ceil(ncap/128)][M][D]
   std::vector<void*> allocs;
   // optional per-kernel HIP-event timing (gdrf_set_timing): events recorded on the launch stream
@@ -156,7 +158,8 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->bf16x6 = 0;
-  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr;
+  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0;
+  c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -274,6 +277,25 @@ int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
     c->Wh = p; c->allocs.push_back(p);
   }
   c->bf16x6 = mode;
+  return 0;
+}
+int gdrf_set_whiten(gdrf_ctx* c, int whiten) {
+  if (whiten != 0 && whiten != 1) return fail(-1, "gdrf_set_whiten", "whiten must be 0 or 1");
+  if (!whiten && c->Tst) return fail(-1, "gdrf_set_whiten", "whiten = 0 needs the dense Wbar form (GDRF_STORE_T_OFF)");
+  HIPCHK(hipSetDevice(c->dev));
+  if (!whiten && !c->uS) {
+    const size_t kmm = (size_t)c->K * c->Mp * c->Mp * c->ssz, kv = (size_t)c->K * c->Mp * c->ssz;
+    void** ps[] = {&c->uS, &c->uSb, &c->uSc, &c->uU, &c->uUb, &c->Uw};
+    const size_t sz[] = {kmm, kmm, kmm, kv, kv, (size_t)c->K * c->M * c->esz};
+    for (int i = 0; i < 6; ++i) {
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, sz[i]);
+      if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(unwhitened scratch)", hipGetErrorString(e));
+      HIPCHK(hipMemset(p, 0, sz[i]));
+      *ps[i] = p; c->allocs.push_back(p);
+    }
+  }
+  c->unwhitened = !whiten;
   return 0;
 }
 int gdrf_set_learn_inducing(gdrf_ctx* c, int on) {
@@ -497,6 +519,21 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
+  // whiten = False: S' = L^-1 S (into c->S / c->ST, and kept in the solve precision in c->uS), u' = L^-1 u (c->Uw, c->uU)
+  static int unwhiten_forward(gdrf_ctx* c, const T* U, hipStream_t s) {
+    const int Mp = c->Mp, M = c->M, K = c->K;
+    const int64_t mm = (int64_t)Mp * Mp;
+    int rc;
+    if ((rc = join_fact(c, s))) return rc;
+    hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((K * mm + 255) / 256)), dim3(256), 0, s, K * mm, (const T*)P(c->ST), Q(c->uSb));
+    if ((rc = mm_nt<TS>(c, Q(c->Linv), 0, Q(c->uSb), mm, Q(c->uS), mm, TS(1), K, s))) return rc;        // S'[i][j] = sum_q Linv[i][q] S[q][j]
+    dim3 g3((Mp + 255) / 256, Mp, K);
+    hipLaunchKernelGGL((cast_with_transpose_kernel<TS, T>), g3, dim3(256), 0, s, (const TS*)Q(c->uS), Mp, P(c->S), P(c->ST));
+    hipLaunchKernelGGL((lower_matvec_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, Q(c->uU),
+                       (T*)c->Uw);
+    return 0;
+  }
+
   static int step_local(gdrf_ctx* c, const T* X, const int32_t* ws, const T* eps, int64_t n, const T* Z, const T* params,
                         T* redT, double* redd, hipStream_t s) {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
@@ -510,6 +547,10 @@ template <typename T, typename TS> struct Impl {
       dim3 g3((Mp + 255) / 256, Mp, K);
       hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
       hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, phi_unc, K, V, P(c->phi));
+      if (c->unwhitened) {
+        if ((rc = unwhiten_forward(c, U, s))) return rc;     // S, ST now hold S' = L^-1 S; c->Uw holds u' = L^-1 u
+        U = (const T*)c->Uw;
+      }
       hipLaunchKernelGGL(build_upad_kernel<T>, dim3((Mp + 255) / 256, GDRF_TILE), dim3(256), 0, s, U, K, M, Mp, P(c->Upad));
       if (!c->Tst && (rc = mm_nt<T>(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
     }
@@ -665,6 +706,16 @@ template <typename T, typename TS> struct Impl {
     hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, mm, GT, Q(c->GTs));
     // HT = GT Linv ; LbarT = -triu(HT)
     if ((rc = mm_nt<TS>(c, Q(c->GTs), 0, Q(c->LinvT), 0, Q(c->t0), 0, TS(1), 1, s))) return rc;
+    if (c->unwhitened) {
+      // Sbar'^T = 2 S'^T A_k (A_k symmetric) -> Sbar = L^-T Sbar' -> P_k = S'_k Sbar_k^T ; ubar = L^-T ubar' ; HT += sum_k (P_k + u'_k ubar_k^T)
+      if ((rc = mm_nt<T>(c, P(c->ST), mm, Ak, mm, P(c->Sbar), mm, T(2), K, s))) return rc;
+      hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((K * mm + 255) / 256)), dim3(256), 0, s, K * mm, (const T*)P(c->Sbar), Q(c->uSb));
+      if ((rc = mm_nt<TS>(c, Q(c->LinvT), 0, Q(c->uSb), mm, Q(c->uSc), mm, TS(1), K, s))) return rc;   // Sbar[q][j] = sum_i LinvT[q][i] Sbar'[i][j]
+      if ((rc = mm_nt<TS>(c, Q(c->uS), mm, Q(c->uSc), mm, Q(c->uSb), mm, TS(1), K, s))) return rc;      // P_k[i][j] = sum_q S'[i][q] Sbar[j][q]
+      hipLaunchKernelGGL((upper_matvec_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), ubar, M, Mp, Q(c->uUb));
+      hipLaunchKernelGGL(add_et_kernel<TS>, dim3((M + 255) / 256, M), dim3(256), 0, s, (const TS*)Q(c->uSb), (const TS*)Q(c->uU),
+                         (const TS*)Q(c->uUb), K, M, Mp, Q(c->t0));
+    }
     hipLaunchKernelGGL(lbar_t_kernel<TS>, g2, dim3(256), 0, s, (const TS*)Q(c->t0), Mp, Q(c->t1));
     // Q = L^T Lbar ; P = Phi(Q)
     if ((rc = mm_nt<TS>(c, Q(c->LT), 0, Q(c->t1), 0, Q(c->t0), 0, TS(1), 1, s))) return rc;
@@ -684,6 +735,9 @@ template <typename T, typename TS> struct Impl {
     hipLaunchKernelGGL(grad_s_kernel<T>, g3, dim3(256), 0, s, P(c->Sbar), P(c->S), M, Mp, -1.0 / n_global, grads + poff(c, 5));
     hipLaunchKernelGGL(grad_small_kernel<T>, dim3(1), dim3(256), 0, s, M, Mp, K, V, c->hyp, redd, c->dsmall, ubar, phib, P(c->phi),
                        c->alpha_dev, c->lgam_const, ll_const, n_global, grads, grads + poff(c, 3), grads + poff(c, 4), c->flag, out_d);
+    if (c->unwhitened)       // overwrite the u_loc / u_scale_tril blocks with the gradients chained through L^-T
+      hipLaunchKernelGGL((grad_unwhitened_kernel<TS, T>), g3, dim3(256), 0, s, (const TS*)Q(c->uSc), (const TS*)Q(c->uUb), params + poff(c, 5), K, M,
+                         Mp, -1.0 / n_global, grads + poff(c, 5), grads + poff(c, 3));
     LAUNCHCHK("step_finish");
     return 0;
   }
@@ -693,6 +747,11 @@ template <typename T, typename TS> struct Impl {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
     const T* U = params + poff(c, 3);
     if (int rcj = join_fact(c, s)) return rcj;
+    if (c->unwhitened) {       // loc = K_nm L^-T (L^-1 u)
+      hipLaunchKernelGGL((lower_matvec_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, Q(c->uU),
+                         (T*)c->Uw);
+      U = (const T*)c->Uw;
+    }
     if (mode >= 2) hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, params + poff(c, 4), K, V, P(c->phi));
     hipLaunchKernelGGL((predict_coeff_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, K, Q(c->Cf));
     size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(TS);

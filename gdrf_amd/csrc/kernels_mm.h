@@ -454,6 +454,64 @@ __global__ void kuu_bar_reduce_kernel(const T* __restrict__ Sp, const T* __restr
   if (threadIdx.x == 0) { part[3 * i] = s1; part[3 * i + 1] = s2; part[3 * i + 2] = s3; }
 }
 
+// ---- whiten = False (pyro conditional's unwhitened branch; sparse_gdrf.py:30): the variational mean and scale factor are
+// given in the space of f(Z): the forward uses u' = L^-1 u and S' = L^-1 S, the backward chains through L^-T and adds the
+// L-dependence of u', S' to Lbar.  All M x M, in the solve precision.
+// out[k][i] = sum_{q <= i} Linv[i][q] U[k][q]   (u' = L^-1 u), written in both precisions
+template <typename T, typename TP>
+__global__ void lower_matvec_kernel(const T* __restrict__ Linv, const TP* __restrict__ U, int M, int Mp, T* __restrict__ outS,
+                                    TP* __restrict__ outP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i >= M) return;
+  T s = 0;
+  for (int q = 0; q <= i; ++q) s += Linv[(int64_t)i * Mp + q] * (T)U[(int64_t)k * M + q];
+  outS[(int64_t)k * Mp + i] = s;
+  outP[(int64_t)k * M + i] = (TP)s;
+}
+// out[k][q] = sum_{i >= q} Linv[i][q] ubar'[k][i]   (ubar = L^-T ubar')
+template <typename T, typename TP>
+__global__ void upper_matvec_kernel(const T* __restrict__ Linv, const TP* __restrict__ ub, int M, int Mp, T* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (q >= M) return;
+  T s = 0;
+  for (int i = q; i < M; ++i) s += Linv[(int64_t)i * Mp + q] * (T)ub[(int64_t)k * Mp + i];
+  out[(int64_t)k * Mp + q] = s;
+}
+// a (solve precision, [K][Mp][Mp]) -> the N-side copies S and S^T
+template <typename T, typename TP>
+__global__ void cast_with_transpose_kernel(const T* __restrict__ a, int Mp, TP* __restrict__ S, TP* __restrict__ ST) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, k = blockIdx.z;
+  if (j >= Mp) return;
+  const TP v = (TP)a[((int64_t)k * Mp + i) * Mp + j];
+  S[((int64_t)k * Mp + i) * Mp + j] = v;
+  ST[((int64_t)k * Mp + j) * Mp + i] = v;
+}
+// HT[i][j] += sum_k ( P[k][i][j] + u'[k][i] * ubar[k][j] ):  the transposed extra term E^T = sum_k (S'_k Sbar_k^T + u'_k ubar_k^T) of
+// Lbar = -tril(L^-T G + E)
+template <typename T>
+__global__ void add_et_kernel(const T* __restrict__ Pk, const T* __restrict__ up, const T* __restrict__ ub, int K, int M, int Mp,
+                              T* __restrict__ HT) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= M || i >= M) return;
+  T s = 0;
+  for (int k = 0; k < K; ++k) s += Pk[((int64_t)k * Mp + i) * Mp + j] + up[(int64_t)k * Mp + i] * ub[(int64_t)k * Mp + j];
+  HT[(int64_t)i * Mp + j] += s;
+}
+// parameter gradients in the unwhitened case: Sbar (= L^-T Sbar', full) through the lower_cholesky transform (diag = exp(unc)),
+// and ubar (= L^-T ubar')
+template <typename T, typename TP>
+__global__ void grad_unwhitened_kernel(const T* __restrict__ Sbar, const T* __restrict__ ub, const TP* __restrict__ Sunc, int K, int M,
+                                       int Mp, double neg_inv_n, TP* __restrict__ gS, TP* __restrict__ gU) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, k = blockIdx.z;
+  if (j >= M) return;
+  const int64_t pi = ((int64_t)k * Mp + i) * Mp + j, gi = ((int64_t)k * M + i) * M + j;
+  double v = 0;
+  if (j < i) v = (double)Sbar[pi];
+  else if (j == i) v = (double)Sbar[pi] * exp((double)Sunc[gi]);
+  gS[gi] = (TP)(neg_inv_n * v);
+  if (i == 0) gU[(int64_t)k * M + j] = (TP)(neg_inv_n * (double)ub[(int64_t)k * Mp + j]);
+}
+
 // gradient of the loss w.r.t. the unconstrained inducing inputs (interval(0,1) constraint = sigmoid; sparse_gdrf.py:79-88):
 //   Zbar[i][d] = 2/ls^2 * ( G[i][d] + 2 * sum_j Kuu_bar[i][j] * dk/dr2(z_i, z_j) * (z_id - z_jd) ),  Kuu_bar = (S' + S'^T)/2,
 // G = the observation-side sums of gemm_nt<BwdKnmProb<.., true>> (all-reduced), then the chain through z = sigmoid(u):

@@ -33,7 +33,7 @@ class Engine:
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
                  device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
-                 store_t="auto", mfma_mode: str = "auto", learn_inducing: bool = False):
+                 store_t="auto", mfma_mode: str = "auto", learn_inducing: bool = False, whiten: bool = True):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -76,6 +76,9 @@ class Engine:
         self.learn_inducing = bool(learn_inducing)
         if self.learn_inducing:
             _lib.check(self.lib.gdrf_set_learn_inducing(self.ctx, 1), "gdrf_set_learn_inducing")
+        self.whiten = bool(whiten)
+        if not self.whiten:
+            _lib.check(self.lib.gdrf_set_whiten(self.ctx, 0), "gdrf_set_whiten")
         red = (C.c_int64 * 6)()
         _lib.check(self.lib.gdrf_red_layout(self.ctx, red), "gdrf_red_layout")
         self.red_layout = dict(ubar=red[0], phibar=red[1], A=red[2], GT=red[3], total_T=red[4], total_d=red[5])

@@ -99,8 +99,6 @@ class SparseMultinomialGDRF:
         if mean_function is not None or link_function is not None:
             raise NotImplementedError("custom mean_function / link_function: the HIP path fuses zero_mean and the softmax link "
                                       "(gdrf/models/abstract_gdrf.py:17-22)")
-        if not whiten:
-            raise NotImplementedError("whiten=False (SURVEY.md 8(f) item 4)")
         if randomize_metric is not None:
             raise NotImplementedError("randomize_metric")
         if not isinstance(kernel, Kernel):
@@ -119,7 +117,7 @@ class SparseMultinomialGDRF:
         self._lower = torch.tensor([b[0] for b in self._world], dtype=torch.float64)
         self._upper = torch.tensor([b[1] for b in self._world], dtype=torch.float64)
         self._delta = self._upper - self._lower
-        self._jitter, self._maxjitter, self._whiten = float(jitter), int(maxjitter), True
+        self._jitter, self._maxjitter, self._whiten = float(jitter), int(maxjitter), bool(whiten)
         self._fixed_inducing_points = bool(fixed_inducing_points)   # False: Z is an interval(0,1)-constrained parameter
         if isinstance(dirichlet_param, float):
             dirichlet_param = torch.tensor(dirichlet_param)
@@ -159,7 +157,7 @@ class SparseMultinomialGDRF:
             return e
         new = Engine(n, self.M, self._K, self._V, self.D, dtype=self.dtype, kernel=self._kernel.name, device=self.device,
                      jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32, mfma_mode=self._mfma_mode,
-                     learn_inducing=not self._fixed_inducing_points)
+                     learn_inducing=not self._fixed_inducing_points, whiten=self._whiten)
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
         if e is None:

@@ -51,6 +51,10 @@ int gdrf_stores_t(const gdrf_ctx* ctx);
  * Wbar form (GDRF_STORE_T_OFF); a fresh context is in mode 0, gdrf_amd.Engine selects 1 for float32 by default. */
 int gdrf_set_mfma_mode(gdrf_ctx* ctx, int mode);
 int gdrf_get_mfma_mode(const gdrf_ctx* ctx);
+/* whiten = 0: the unwhitened branch of pyro's gp.util.conditional (gdrf/models/sparse_gdrf.py:30,175-185: the
+ * constructor's `whiten` argument): u_loc and u_scale_tril parameterise q(f(Z)) itself, the predictive uses
+ * L^-1 u_loc and L^-1 u_scale_tril.  Default 1 (whitened), which is what the reference's train() always runs. */
+int gdrf_set_whiten(gdrf_ctx* ctx, int whiten);
 /* Learnable inducing inputs (gdrf/models/sparse_gdrf.py:79-88, fixed_inducing_points=False: a PyroParam under
  * stack([interval(0, 1)] * D), i.e. Z = sigmoid(unconstrained)).  The flat parameter vector always carries an (M, D)
  * block for the unconstrained values, gdrf_inducing_layout -> {offset, M*D}; the caller evaluates Z = sigmoid(block) and

@@ -111,7 +111,7 @@ def jitter_total(jitter: float, level: int) -> float:
 # --------------------------------------------------------------------------
 # pyro.contrib.gp.util.conditional, full_cov=False, whiten=True  
 # --------------------------------------------------------------------------
-def conditional(kind, Xnew, Z, lengthscale, variance, u_loc, u_scale_tril, Lff, scale_mixture=None):
+def conditional(kind, Xnew, Z, lengthscale, variance, u_loc, u_scale_tril, Lff, scale_mixture=None, whiten=True):
     M = Z.size(0)
     K = u_loc.size(0)
     N = Xnew.size(0)
@@ -119,6 +119,11 @@ def conditional(kind, Xnew, Z, lengthscale, variance, u_loc, u_scale_tril, Lff, 
     v_2D = u_loc.reshape(-1, M).t()                                      # (M,K)
     S_2D = u_scale_tril.reshape(-1, M, M).permute(1, 2, 0).reshape(M, -1)  # (M, M*K): col = j*K + k
     W = torch.linalg.solve_triangular(Lff, Kfs, upper=False).t()         # (N,M)
+    if not whiten:
+        # pyro conditional, whiten=False branch: [f_loc, Kfs, f_scale_tril] are packed and solved against Lff together, i.e.
+        # the mean and the scale factor are given in the unwhitened space: v = Lff^-1 f_loc, S = Lff^-1 f_scale_tril
+        v_2D = torch.linalg.solve_triangular(Lff, v_2D, upper=False)
+        S_2D = torch.linalg.solve_triangular(Lff, S_2D, upper=False)
     loc = W.matmul(v_2D).t().reshape(K, N)
     Kssdiag = kernel_diag(Xnew, variance)
     Qssdiag = W.pow(2).sum(dim=-1)
@@ -164,7 +169,8 @@ class RefShapedGDRF:
     def __init__(self, xs, ws, *, kind="rbf", K=3, n_points=(8, 4), lengthscale=0.1, variance=25.0,
                  dirichlet_param=0.01, jitter=1e-8, maxjitter=15, noise=1.0, dtype=torch.float64,
                  Z: Optional[torch.Tensor] = None, optimizer="adam", lr=1e-3,
-                 force_jitter_level: Optional[int] = None, learn_inducing: bool = False, scale_mixture: float = 1.0):
+                 force_jitter_level: Optional[int] = None, learn_inducing: bool = False, scale_mixture: float = 1.0,
+                 whiten: bool = True):
         self.dtype = dtype
         self.kind = kind
         self.K = K
@@ -196,6 +202,7 @@ class RefShapedGDRF:
         }
         if kind == "rationalquadratic":
             self.params["log_scale_mixture"] = sm.log().clone()          # positive constraint -> exp
+        self.whiten = bool(whiten)
         self.learn_inducing = bool(learn_inducing)
         if self.learn_inducing:
             # sparse_gdrf.py:79-88: PyroParam(scaled points, constraint=stack([interval(0, 1)] * D)); the stored value is
@@ -245,14 +252,14 @@ class RefShapedGDRF:
         # guide: sparse_gdrf.py:375-409
         Luu = self._luu(c)
         f_loc, f_var = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
-                                   c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"])
+                                   c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"], self.whiten)
         q_mu = Normal(f_loc, f_var)                       # Q1: variance passed as scale
         mu = f_loc + f_var * eps                          # rsample with injected eps
         lq_mu = q_mu.log_prob(mu).sum()
         # model (replayed with mu, phi): sparse_gdrf.py:323-373
         Luu2 = self._luu(c)
         f_loc2, f_var2 = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
-                                     c["u_loc"], c["u_scale_tril"], Luu2, c["scale_mixture"])
+                                     c["u_loc"], c["u_scale_tril"], Luu2, c["scale_mixture"], self.whiten)
         lp_mu = Normal(f_loc2, f_var2 + c["noise"]).log_prob(mu).sum()
         lp_phi = Dirichlet(self.alpha).log_prob(c["phi"]).sum()
         topic_probs = torch.softmax(mu, -2).transpose(-2, -1)
@@ -313,7 +320,7 @@ class RefShapedGDRF:
         c = self.constrained()
         Luu = self._luu(c)
         f_loc, _ = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
-                               c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"])
+                               c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"], self.whiten)
         return f_loc
 
     def topic_probs(self, xs=None):

@@ -409,3 +409,33 @@ def test_renyi_elbo_matches_the_oracle(alpha):
     assert abs(out["loss"] - loss) < LOSS_TOL_VS_TORCH * abs(loss)
     for name in eng.PARAM_NAMES:
         assert relerr(eng.view(name, eng.grads).cpu().numpy(), grads[name].numpy()) < 1e-7, name
+
+
+# ---- whiten = False (sparse_gdrf.py:30; the unwhitened branch of pyro's conditional) ---------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_unwhitened_variational_parameters_match_the_oracle(dtype):
+    """u' = L^-1 u, S' = L^-1 S in the forward; gradients chained through L^-T and the extra L-dependence into the Cholesky
+    backward.  fp64: every gradient and the predictive against autograd; fp32 (default build): against the fp64 oracle at
+    the same parameters."""
+    m, eps = make_oracle(dtype=torch.float64, whiten=False, W=24, H=15, V=10, K=3, n_points=(5, 4), jitter=1e-6, lengthscale=0.25)
+    with torch.no_grad():                       # make u_loc / u_scale_tril generic (not the init L) so that every term is exercised
+        g = torch.Generator().manual_seed(3)
+        m.params["u_loc"].add_(0.5 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64))
+    loss, grads = m.loss_and_grads(eps)
+    eng = engine_from_oracle(m, dtype=dtype)
+    assert not eng.whiten
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    eng.loss_and_grads(xs, ws, dev(eps, eng), force_level=m.last_jitter_level if dtype == torch.float64 else None)
+    out = eng.read_out()
+    tol_l, tol_g = (LOSS_TOL_VS_TORCH, 1e-8) if dtype == torch.float64 else (5e-6, 3e-3)
+    assert abs(out["loss"] - loss) < tol_l * abs(loss)
+    for name in eng.PARAM_NAMES:
+        got, ref = eng.view(name, eng.grads).cpu().double().numpy(), grads[name].numpy()
+        assert np.abs(got - ref).max() < tol_g * max(np.abs(ref).max(), 1e-6), name
+    tp = eng.predict(xs, 1).cpu().double().numpy()
+    assert np.abs(tp - m.topic_probs().numpy()).max() < (1e-10 if dtype == torch.float64 else 1e-5)
+    # and it is a different model from the whitened one at the same numbers
+    m2, _ = make_oracle(dtype=torch.float64, whiten=True, W=24, H=15, V=10, K=3, n_points=(5, 4), jitter=1e-6, lengthscale=0.25)
+    for k in m2.params:
+        m2.params[k].data.copy_(m.params[k].data)
+    assert abs(m2.loss_and_grads(eps)[0] - loss) > 1e-3 * abs(loss)
