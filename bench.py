@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--jitter", type=float, default=1e-6)
     ap.add_argument("--cpu-baseline-n", type=int, default=20000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
-    ap.add_argument("--knm-iters", type=int, default=20)
+    ap.add_argument("--knm-iters", type=int, default=50)
     ap.add_argument("--seed", type=int, default=777)
     ap.add_argument("--mfma-mode", default="auto", choices=["auto", "f32", "bf16x6"],
                     help="arithmetic of the f32 GEMM-shaped contractions: exact-split emulation on bf16 MFMA (the default for "
@@ -185,7 +185,8 @@ def main():
 
     # ---- standalone K_nm kernel (HBM roofline), same shard
     knm_out = torch.empty(xs.shape[0], M, dtype=dtype, device=device)
-    eng.knm_into(xs, knm_out)
+    for _ in range(5):                       # untimed: the first launches after the step loop run 10-15 % slow
+        eng.knm_into(xs, knm_out)
     eng.set_timing(True)
     for _ in range(args.knm_iters):
         eng.knm_into(xs, knm_out)

@@ -49,6 +49,47 @@ __global__ __launch_bounds__(256) void knm_kernel(const TX* __restrict__ X, int6
       for (int d = 0; d < GDRF_DMAX; ++d) z[e][d] = (i0 + e < M && d < D) ? Z[(int64_t)(i0 + e) * D + d] : T(0);
     const int64_t stride = (int64_t)gridDim.x * rpp;
     const bool vec_ok = aligned && (i0 + VE <= ldo);
+#ifndef GDRF_KNM_NO_RBF_FAST
+    if constexpr (FAST && sizeof(T) == 4) {
+      if (kind == 0) {
+        // RBF on the roofline path: k = var * exp(-r2 / (2 ls^2)) = 2^(log2 var - sum_d (a x_d - a z_d)^2), a = sqrt(log2(e) / 2) / ls:
+        // with the coordinates pre-scaled by a (the inducing points once per thread, x once per row) an element costs
+        // D subtractions, D fused multiply-adds and one v_exp_f32 instead of ~9 VALU operations - the kernel is a 2 GB
+        // streaming store, but at ~5 TB/s its VALU work was a third of its time.
+        const float a = sqrtf(0.5f * 1.44269504088896f * (float)ils2), lv = __log2f((float)var);
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+#pragma unroll
+          for (int d = 0; d < GDRF_DMAX; ++d) z[e][d] *= a;
+        for (int64_t row0 = (int64_t)blockIdx.x * rpp + rsub; row0 < N; row0 += 4 * stride) {
+          float x[4][GDRF_DMAX];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u * stride;
+#pragma unroll
+            for (int d = 0; d < GDRF_DMAX; ++d) x[u][d] = (row < N && d < D) ? a * (float)X[row * D + d] : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u * stride;
+            if (row >= N) break;
+            V o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+              float t = -lv;
+#pragma unroll
+              for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const float dd = x[u][d] - z[e][d]; t = fmaf(dd, dd, t); }
+              o[e] = (i0 + e < M) ? __builtin_amdgcn_exp2f(-t) : 0.0f;
+            }
+            T* orow = out + row * ldo;
+            if (vec_ok) { if (NT) __builtin_nontemporal_store(o, reinterpret_cast<V*>(orow + i0)); else *reinterpret_cast<V*>(orow + i0) = o; }
+            else for (int e = 0; e < VE; ++e) if (i0 + e < ldo) orow[i0 + e] = o[e];
+          }
+        }
+        return;
+      }
+    }
+#endif
     for (int64_t row0 = (int64_t)blockIdx.x * rpp + rsub; row0 < N; row0 += 4 * stride) {
       T x[4][GDRF_DMAX];
 #pragma unroll
