@@ -439,3 +439,28 @@ def test_unwhitened_variational_parameters_match_the_oracle(dtype):
     for k in m2.params:
         m2.params[k].data.copy_(m.params[k].data)
     assert abs(m2.loss_and_grads(eps)[0] - loss) > 1e-3 * abs(loss)
+
+
+def test_three_dimensional_world_with_learnable_inducing_points():
+    """D = 3 (e.g. two spatial coordinates and time; the reference takes any len(world)): loss and every gradient, incl. the
+    inducing inputs', fp64 against autograd."""
+    from oracle.gdrf_oracle import RefShapedGDRF
+    g = torch.Generator().manual_seed(21)
+    N, V, K = 700, 9, 3
+    xs = torch.rand(N, 3, generator=g, dtype=torch.float64)
+    ws = torch.randint(0, 6, (N, V), generator=g, dtype=torch.int32)
+    Z = 0.1 + 0.8 * torch.rand(18, 3, generator=g, dtype=torch.float64)
+    m = RefShapedGDRF(xs, ws, kind="matern52", K=K, n_points=(3, 3, 2), Z=Z, lengthscale=0.4, jitter=1e-6, learn_inducing=True,
+                      dtype=torch.float64)
+    with torch.no_grad():
+        m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64))
+        m.params["phi_unc"].add_(0.5 * torch.randn(m.params["phi_unc"].shape, generator=g, dtype=torch.float64))
+    eps = torch.randn(K, N, generator=g, dtype=torch.float64)
+    loss, grads = m.loss_and_grads(eps)
+    eng = engine_from_oracle(m)
+    assert eng.D == 3
+    eng.loss_and_grads(dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=m.last_jitter_level)
+    assert abs(eng.read_out()["loss"] - loss) < LOSS_TOL_VS_TORCH * abs(loss)
+    for name in eng.param_names:
+        got, ref = eng.view(name, eng.grads).cpu().numpy(), grads[name].numpy()
+        assert np.abs(got - ref).max() < 1e-8 * max(np.abs(ref).max(), 1e-6), name
