@@ -452,7 +452,7 @@ template <typename T, typename TS> struct Impl {
       const int64_t nb = (int64_t)K * Mp * Mp, nw = n * Mp;
       {
         ScopedTimer tm(c, 2, s);
-        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->ST, nb, (__bf16*)c->STh, nb);
+        hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->ST, nb, Mp, Mp, (__bf16*)c->STh, nb);
         hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nw / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->W, nw, (__bf16*)c->Wh,
                            (int64_t)c->ncap * Mp);
       }
@@ -490,7 +490,7 @@ template <typename T, typename TS> struct Impl {
     if constexpr (std::is_same<T, float>::value) {
       const int Mp = c->Mp, K = c->K;
       const int64_t nb = (int64_t)K * Mp * Mp;
-      hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, (__bf16*)c->Bh, nb);
+      hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, Mp, Mp, (__bf16*)c->Bh, nb);
       BwdWbarBf16Args a{(const float*)c->W, (const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, c->M, Mp, K, (const __bf16*)c->Bh, nb,
                         (const float*)c->vbar, (const float*)c->locbar, c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar};
       const size_t lds = Bf16x6Cfg::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(float);

@@ -59,10 +59,29 @@ __global__ void split3_kernel(const float* __restrict__ in, int64_t n, __bf16* _
   *reinterpret_cast<bf16x4*>(out + 2 * stride + i) = l;
 }
 
+// the same pieces in k-blocked order for the NT kernels' small operands (B_k, S_k^T):  in[b][r][c] (b < nb, r < R, c < C, C a
+// multiple of 32)  ->  out[p][b][c / 32][r][c % 32].  A tile's 32-wide reduction chunk is then ONE contiguous block of whole
+// 128-byte lines (rows x 64 B), instead of 64 B out of every 1 KB row: the row-major form left the load path saturated
+// (measured: ~4000 cycles per prefetched load, 1500 of every 4600 cycles per chunk spent waiting for them).
+__global__ void split3_blocked_kernel(const float* __restrict__ in, int64_t n, int R, int C, __bf16* __restrict__ out, int64_t stride) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const f32x4 x = *reinterpret_cast<const f32x4*>(in + i);
+  bf16x4 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(x[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
+  const int64_t rc = (int64_t)R * C, b = i / rc, rem = i - b * rc;
+  const int r = (int)(rem / C), c = (int)(rem - (int64_t)r * C);
+  const int64_t o = b * rc + ((int64_t)(c >> 5) * R + r) * 32 + (c & 31);
+  *reinterpret_cast<bf16x4*>(out + o) = h;
+  *reinterpret_cast<bf16x4*>(out + stride + o) = m;
+  *reinterpret_cast<bf16x4*>(out + 2 * stride + o) = l;
+}
+
 struct BwdWbarBf16Args {
   const float* W; const __bf16* Wh; int64_t w_stride;   // W (f32, epilogue) and its 3 bf16 pieces [p][row][Mp]
   int64_t nrows; int M, Mp, K;
-  const __bf16* Bh; int64_t piece_stride;     // Bh[p][k][col][i], piece_stride = K*Mp*Mp
+  const __bf16* Bh; int64_t piece_stride;     // Bh[p][k][i / 32][col][i % 32] (k-blocked), piece_stride = K*Mp*Mp
   const float* vbar; const float* locbar; int64_t ldk;
   const float* asum; const float* U; float* Wbar;
 };
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args
       const int col = (n0 + row < Mp) ? n0 + row : 0;     // likewise: columns >= Mp are never stored
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        rb[p][j] = *reinterpret_cast<const bf16x8*>(g.Bh + p * g.piece_stride + ((int64_t)rep * Mp + col) * Mp + kA + kq);
+        rb[p][j] = *reinterpret_cast<const bf16x8*>(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + kq);
     }
   };
   auto store_a = [&]() {
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args
 struct FwdTBf16Args {
   const __bf16* Wh; int64_t w_stride; int64_t nrows; int Mp, K;
   int KG; int rt8;                            // topics per group (see the block map), ceil(row tiles / 8)
-  const __bf16* STh; int64_t piece_stride;    // STh[p][k][j][i] = pieces of S_k[i][j]
+  const __bf16* STh; int64_t piece_stride;    // STh[p][k][i / 32][j][i % 32] = pieces of S_k[i][j] (k-blocked)
   float* tt; int64_t ldt;
 };
 
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void fwd_t_bf16x6_kernel(FwdTBf16Args g) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           ra[p][j] = *reinterpret_cast<const bf16x8*>(g.Wh + p * g.w_stride + row * Mp + kA + kq);
-          const u32x4 raw = *reinterpret_cast<const u32x4*>(g.STh + p * g.piece_stride + ((int64_t)bz * Mp + col) * Mp + kA + kq);
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + kq);
           const u32x4 msk = cok ? raw : u32x4{0, 0, 0, 0};
           rb[p][j] = __builtin_bit_cast(bf16x8, msk);
         }
