@@ -493,11 +493,17 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, Mp, Mp, (__bf16*)c->Bh, nb);
       BwdWbarBf16Args a{(const float*)c->W, (const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, c->M, Mp, K, (const __bf16*)c->Bh, nb,
                         (const float*)c->vbar, (const float*)c->locbar, c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar};
-      const size_t lds = Bf16x6Cfg::LDS_BYTES + (size_t)K * GDRF_TILE * sizeof(float);
-      if (lds > 160 * 1024) return fail(-1, "wbar_bf16x6", "too many topics for the LDS scale table");
+      const size_t grp = Bf16x6Cfg::LDS_BYTES + (((size_t)K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15);
       const int nct_ = (Mp + GDRF_TILE - 1) / GDRF_TILE;
-      HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel, dim3((unsigned)round_up(rtiles * nct_, 8)), dim3(256), lds, s, a);
+      if (K >= 2 && 2 * grp <= 160 * 1024) {   // two phase-shifted wave groups per workgroup (own A images, shared double-buffered B, LDS-DMA staging)
+        const int64_t pairs = (rtiles + 1) / 2;
+        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * grp)));
+        hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel<2>, dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), 2 * grp, s, a);
+      } else {
+        if (grp > 160 * 1024) return fail(-1, "wbar_bf16x6", "too many topics for the LDS scale table");
+        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grp));
+        hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel<1>, dim3((unsigned)round_up(rtiles * nct_, 8)), dim3(256), grp, s, a);
+      }
       LAUNCHCHK("wbar_bf16x6");
       return 0;
     } else {

@@ -86,18 +86,45 @@ struct BwdWbarBf16Args {
   const float* asum; const float* U; float* Wbar;
 };
 
-__global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args g) {
+// NG = 1: one 256-thread workgroup per tile, two workgroups per CU (they share the CU's SIMDs at random).
+// NG = 2: one 512-thread workgroup per CU holding TWO such tiles, one per wave group (waves 0-3 / 4-7: a workgroup's waves
+// go to the SIMDs cyclically, so every SIMD hosts one wave of each group), run phase-shifted on purpose: in every phase one
+// group multiplies its staged chunk while the other moves its next chunk from registers to LDS and issues the loads of the
+// one after, then they swap.  Measured cause (s_memtime per wave, NG = 1): the multiply phase is 1810 cycles (MFMA 1536) but
+// every wave then waits ~1500 cycles at the barrier - each SIMD's two waves contend for the matrix pipe at random and the
+// barrier paces a workgroup by its unluckiest wave.  With the groups alternating, the multiplying wave has its SIMD's pipe
+// to itself and the staging hides behind it.  The phase barrier is a raw s_barrier after s_waitcnt lgkmcnt(0): a
+// __syncthreads() would also drain vmcnt and wait for the prefetch just issued.
+template <int NG>
+__global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args g) {
   using CF = Bf16x6Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem);               // [3][128][LDH]
-  __bf16* Bs = As + 3 * CF::PIECE;                            // [3][128][LDH]
-  float* scaleS = reinterpret_cast<float*>(smem + CF::LDS_BYTES);   // [K][128]  2 vbar_kn
+  const int gp = NG == 2 ? (int)(threadIdx.x >> 8) : 0;
+  // LDS: NG = 1: [A][B][scale];  NG = 2: [A of group 0][A of group 1][B buffer 0][B buffer 1][scale 0][scale 1] - the two
+  // groups work on the same column tile, so the B chunk is staged ONCE (by group 1) into a double-buffered image both read
+  constexpr int IMG = 3 * CF::PIECE;                          // halfwords per operand image
+  const size_t tab = ((size_t)g.K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15;
+  __bf16* As = reinterpret_cast<__bf16*>(smem) + (NG == 2 ? gp * IMG : 0);              // [3][128][LDH]
+  __bf16* Bs = reinterpret_cast<__bf16*>(smem) + (NG == 2 ? 2 * IMG : IMG);             // [NG][3][128][LDH]
+  float* scaleS = reinterpret_cast<float*>(smem + (size_t)(NG == 2 ? 4 : 2) * IMG * 2 + (size_t)gp * tab);  // [K][128]  2 vbar_kn
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   const int nct = (g.Mp + GDRF_TILE - 1) / GDRF_TILE;
   int64_t rtile; int ct;
-  NTXcdMap{}.map_block(blockIdx.x, nct, false, rtile, ct);
+  if constexpr (NG == 1) {
+    NTXcdMap{}.map_block(blockIdx.x, nct, false, rtile, ct);
+  } else {        // the same XCD <-> column tile affinity; the two groups take adjacent row tiles of one column tile
+    const unsigned w = blockIdx.x;
+    if (nct <= 8 && (8 % nct) == 0 && (gridDim.x % 8u) == 0) {
+      const unsigned xcd = w & 7u, idx = w >> 3, per = 8u / (unsigned)nct;
+      ct = (int)(xcd % (unsigned)nct);
+      rtile = 2 * ((int64_t)idx * per + xcd / (unsigned)nct) + gp;
+    } else {
+      ct = (int)(w % (unsigned)nct);
+      rtile = 2 * (int64_t)(w / (unsigned)nct) + gp;
+    }
+  }
   const int64_t m0 = rtile * GDRF_TILE;
   const int n0 = ct * GDRF_TILE;
   const int K = g.K, Mp = g.Mp;
@@ -143,12 +170,12 @@ __global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args
       for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(As + p * CF::PIECE + off) = ra[p][j];
     }
   };
-  auto store_b = [&]() {
+  auto store_b = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int v = tid + 256 * j, off = bf16x6_off(v >> 2, (v & 3) * 8);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(Bs + p * CF::PIECE + off) = rb[p][j];
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(Bs + (buf * 3 + p) * CF::PIECE + off) = rb[p][j];
     }
   };
   // one staged chunk: P = A B^T through the six cross products (small terms first), then acc += diag(scale) P.
@@ -162,21 +189,21 @@ __global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args
 #pragma unroll
       for (int p = 0; p < 3; ++p) fa[a][p] = *reinterpret_cast<const bf16x8*>(As + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
   };
-  auto read_b = [&](bf16x8 (&fb)[3], int b) {
+  auto read_b = [&](bf16x8 (&fb)[3], int b, int buf) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(Bs + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+    for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(Bs + (buf * 3 + p) * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
   };
-  auto compute = [&](const float* sc_row /* scaleS + rep*128, or nullptr for scale 1 */) {
+  auto compute = [&](const float* sc_row /* scaleS + rep*128, or nullptr for scale 1 */, int buf) {
     f32x4 s4[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
       s4[a] = sc_row ? *reinterpret_cast<const f32x4*>(sc_row + wr * 64 + a * 16 + lg * 4) : f32x4{1, 1, 1, 1};   // rows 4*lg + r
     bf16x8 fbq[2][3];                      // the next column group's fragments are read while this one multiplies
-    read_b(fbq[0], 0);
+    read_b(fbq[0], 0, buf);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       bf16x8 (&fb)[3] = fbq[b & 1];
-      if (b + 1 < 4) read_b(fbq[(b + 1) & 1], b + 1);
+      if (b + 1 < 4) read_b(fbq[(b + 1) & 1], b + 1, buf);
       f32x4 P[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[2], f32x4{0, 0, 0, 0}, 0, 0, 0);
@@ -198,21 +225,93 @@ __global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args
   };
 
   const int nk = Mp / CF::BK, nchunks = nk * K;
-  load_a(0);
-  load_b(0, 0);
-  for (int c = 0; c < nchunks; ++c) {
-    const int q = c / K, rep = c - q * K;
-    __syncthreads();
-    if (rep == 0) store_a();
-    store_b();
-    __syncthreads();
-    if (c + 1 < nchunks) {
-      const int q1 = (c + 1) / K, rep1 = (c + 1) - q1 * K;
-      if (rep1 == 0) load_a(q1 * CF::BK);
-      load_b(q1 * CF::BK, rep1);
+  if constexpr (NG == 1) {
+    load_a(0);
+    load_b(0, 0);
+    for (int c = 0; c < nchunks; ++c) {
+      const int q = c / K, rep = c - q * K;
+      __syncthreads();
+      if (rep == 0) store_a();
+      store_b(0);
+      __syncthreads();
+      if (c + 1 < nchunks) {
+        const int q1 = (c + 1) / K, rep1 = (c + 1) - q1 * K;
+        if (rep1 == 0) load_a(q1 * CF::BK);
+        load_b(q1 * CF::BK, rep1);
+      }
+      if (rep == 0) read_a();
+      compute(scaleS + rep * GDRF_TILE, 0);
     }
-    if (rep == 0) read_a();
-    compute(scaleS + rep * GDRF_TILE);
+  } else {
+    // Staging by LDS-DMA (global_load_lds_dwordx4: no destination registers, no ds_write - a staging wave's ds_write_b128
+    // were measured starving, ~1600 cycles for six, while its SIMD's other wave streams MFMAs).  One wave-instruction moves a
+    // 16-row block of one piece image, 1 KB: lane l lands at block + 16 l = row l>>2, physical quad l&3, so its SOURCE is
+    // logical quad (l&3) ^ swz(row) - the image swizzle goes on the global address (cdna_hip_programming.md 5.4 rule 21).
+    const int drow = lane >> 2, dq = ((lane & 3) ^ bf16x6_swz(drow)) * 8;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma_b = [&](int c) {             // B chunk c -> buffer c & 1; this wave moves row blocks wave and wave + 4 of each piece
+      if (c >= nchunks) return;
+      const int q = c / K, rep = c - q * K;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbk = wave + 4 * i, row = rbk * 16 + drow;
+        const int col = (n0 + row < Mp) ? n0 + row : 0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          __builtin_amdgcn_global_load_lds((gptr_t)(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + q) * Mp + col) * 32 + dq),
+                                           (lptr_t)(Bs + ((c & 1) * 3 + p) * CF::PIECE + rbk * 512), 16, 0, 0);
+      }
+    };
+    auto dma_a = [&](int q) {             // this group's A image for reduction block q
+      if (q >= nk) return;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbk = wave + 4 * i;
+        int64_t row = m0 + rbk * 16 + drow;
+        row = row < g.nrows ? row : 0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          __builtin_amdgcn_global_load_lds((gptr_t)(g.Wh + p * g.w_stride + row * Mp + q * CF::BK + dq),
+                                           (lptr_t)(As + p * CF::PIECE + rbk * 512), 16, 0, 0);
+      }
+    };
+    auto mult = [&](int c) {
+      const int q = c / K, rep = c - q * K;
+      if (rep == 0) read_a();
+      compute(scaleS + rep * GDRF_TILE, c & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMAs this group issued one phase ago have had a whole phase
+    };
+    auto phase_barrier = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads are done; a DMA just issued stays in flight
+      __builtin_amdgcn_s_barrier();
+    };
+    // Chunk t is multiplied by group 0 in phase 2t and by group 1 in phase 2t+1, both from B buffer t & 1 and their own A
+    // image (whose fragments then stay in registers for the K topic reps).  DMAs are issued in a group's idle phase, land
+    // during its next multiply phase, are retired by the vmcnt(0) that ends it, and are first read a barrier later:
+    //   group 1, phase 2u   : B chunk u+1 -> buffer (u+1)&1 (last read in phase 2u-1); its own A if chunk u+1 opens a block
+    //   group 0, phase 2u+1 : its own A if chunk u+2 opens a block (needed in phase 2u+4; image last read >= 2 phases ago, K >= 2)
+    dma_a(0);
+    if (gp == 1) dma_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase_barrier();
+    for (int ph = 0; ph < 2 * nchunks; ++ph) {
+      const int t = ph >> 1;
+      if ((ph & 1) == gp) {
+        mult(t);
+        phase_barrier();
+        } else if (gp == 0) {
+        const int c = t + 2;
+        if (c < nchunks && c % K == 0) dma_a(c / K);
+          phase_barrier();
+        } else {
+        const int c = t + 1;
+        dma_b(c);
+        if (c < nchunks && c % K == 0) dma_a(c / K);
+          phase_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // rank-K epilogue term locbar^T U as extra chunk(s), split on the fly
   for (int x = 0; x * CF::BK < K; ++x) {
@@ -230,22 +329,43 @@ __global__ __launch_bounds__(256, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args
     }
     __syncthreads();
     read_a();
-    compute(nullptr);
+    compute(nullptr, 0);
   }
-  // Wbar = acc - 2 asum W
+  // Wbar = acc - 2 asum W.  The MFMA accumulator layout (a lane owns one column of four rows) would make this 64 scalar
+  // loads of W and 64 scalar stores per lane in a dependent sequence - measured ~300k cycles per workgroup, a third of its
+  // lifetime.  Instead each wave transposes its 64 x 64 quadrant through a private LDS tile, 32 rows at a time, and moves whole
+  // 256-byte row segments: 16 float4 loads and 16 float4 stores per lane.
+  __syncthreads();                                           // every wave is done with the operand images
+  {
+    constexpr int TS = 68;                                   // tile row stride in floats (272 B: 16-byte aligned, bank-shifted)
+    float* tile = reinterpret_cast<float*>(smem) + (size_t)((NG == 2 ? gp * 4 : 0) + wave) * (32 * TS);
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t m = m0 + wr * 64 + a * 16 + lg * 4 + r;
-      if (m >= g.nrows) continue;
-      const float as2 = 2.0f * g.asum[m];
+      for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wc * 64 + b * 16 + lr;
-        if (n < Mp) g.Wbar[m * Mp + n] = acc[a][b][r] - as2 * g.W[m * Mp + n];
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[(a2 * 16 + lg * 4 + r) * TS + b * 16 + lr] = acc[2 * h + a2][b][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave writes and reads: LDS is in order per wave
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = (lane >> 4) + 4 * i, cv = (lane & 15) * 4;
+        const int64_t m = m0 + wr * 64 + h * 32 + rr;
+        const int n = n0 + wc * 64 + cv;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + rr * TS + cv);
+        if (m < g.nrows && n < Mp) {                         // Mp is a multiple of 32: a float4 never straddles the edge
+          const float as2 = 2.0f * g.asum[m];
+          const f32x4 w = *reinterpret_cast<const f32x4*>(g.W + m * Mp + n);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = t[e] - as2 * w[e];
+          *reinterpret_cast<f32x4*>(g.Wbar + m * Mp + n) = o;
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the tile is overwritten with the other half
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
