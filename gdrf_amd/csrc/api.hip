@@ -460,10 +460,13 @@ template <typename T, typename TS> struct Impl {
       // topics per group: as many lower-triangular S^T piece panels (3 x ~0.6 Mp^2 halfwords each) as fit in 2 MB
       const double panel = 0.625 * 6.0 * (double)Mp * Mp;
       const int KG = std::max(1, std::min(K, (int)(2.0 * 1024 * 1024 / panel)));
-      FwdTBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, (int)((rtiles + 7) / 8),
-                     (const __bf16*)c->STh, nb, (float*)c->tt, c->ldk};
-      HIPCHK(hipFuncSetAttribute((const void*)fwd_t_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Bf16x6Cfg::LDS_BYTES));
-      hipLaunchKernelGGL(fwd_t_bf16x6_kernel, dim3((unsigned)(8 * K * ((rtiles + 7) / 8))), dim3(256), Bf16x6Cfg::LDS_BYTES, s, a);
+      // two row tiles per 512-thread workgroup (two phase-shifted wave groups, LDS-DMA staging): 6 operand images of 24 KB
+      const int64_t pairs = (rtiles + 1) / 2;
+      const int rt8 = (int)((pairs + 7) / 8);
+      FwdTBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, rt8, (const __bf16*)c->STh, nb, (float*)c->tt, c->ldk};
+      constexpr int lds2 = 6 * 3 * Bf16x6Cfg::PIECE * 2;
+      HIPCHK(hipFuncSetAttribute((const void*)fwd_t_bf16x6_2g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+      hipLaunchKernelGGL(fwd_t_bf16x6_2g_kernel, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
       LAUNCHCHK("fwd_t_bf16x6");
       return 0;
     } else {

@@ -493,6 +493,180 @@ __global__ __launch_bounds__(256, 2) void fwd_t_bf16x6_kernel(FwdTBf16Args g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// tt in the two-group LDS-DMA structure of bwd_wbar_bf16x6_kernel<2>: a 512-thread workgroup holds two adjacent row tiles of
+// one topic, one per wave group; both walk the same (column tile, reduction chunk) sequence, so the S_k^T chunk is staged once
+// (by group 1) into a double-buffered image both read, and every group double-buffers its own W chunk.  Chunk c is multiplied
+// by group 0 in phase 2c and by group 1 in phase 2c+1; DMAs are issued in a group's idle phase two chunks ahead (group 0) / one
+// chunk ahead (group 1), land during its next multiply phase and are retired by the vmcnt(0) that ends it.
+// Grid: 8 * K * rt8 with rt8 = ceil(row-tile pairs / 8); block map as fwd_t_bf16x6_kernel with pairs for row tiles.
+__global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g) {
+  using CF = Bf16x6Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = 3 * CF::PIECE;                          // halfwords per operand image
+  const int gp = (int)(threadIdx.x >> 8);
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  __bf16* As = reinterpret_cast<__bf16*>(smem) + gp * 2 * IMG;      // [2 buffers][3][128][32] of this group
+  __bf16* Bs = reinterpret_cast<__bf16*>(smem) + 4 * IMG;           // [2 buffers][3][128][32] shared
+  const int Mp = g.Mp;
+  const int nct = (Mp + GDRF_TILE - 1) / GDRF_TILE;
+  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned per_group = (unsigned)g.KG * (unsigned)g.rt8;
+  const int grp = (int)(idx / per_group);
+  const unsigned rem = idx - (unsigned)grp * per_group;
+  const int kg = min(g.KG, g.K - grp * g.KG);
+  const int64_t rtile = 2 * ((int64_t)(rem / (unsigned)kg) * 8 + xcd) + gp;
+  const int bz = grp * g.KG + (int)(rem % (unsigned)kg);
+  const int64_t m0 = rtile * GDRF_TILE;                        // a tile past the end runs on clamped rows; its tt is never stored
+
+  int nch = 0;                                                 // chunks of the triangular walk: column tile ct covers k in [128 ct, Mp)
+  for (int ct = 0; ct < nct; ++ct) nch += (Mp - ct * GDRF_TILE) / CF::BK;
+  auto decode = [&](int c, int& ct, int& kA, bool& first, bool& last) {
+    for (ct = 0;; ++ct) {
+      const int len = (Mp - ct * GDRF_TILE) / CF::BK;
+      if (c < len) { kA = ct * GDRF_TILE + c * CF::BK; first = c == 0; last = c == len - 1; return; }
+      c -= len;
+    }
+  };
+  const int drow = lane >> 2, dq = ((lane & 3) ^ bf16x6_swz(drow)) * 8;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma_b = [&](int c) {
+    if (c >= nch) return;
+    int ct, kA; bool f, l;
+    decode(c, ct, kA, f, l);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbk = wave + 4 * i, row = rbk * 16 + drow;
+      const int col = (ct * GDRF_TILE + row < Mp) ? ct * GDRF_TILE + row : 0;      // columns >= Mp are skipped when the tile is folded
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + dq),
+                                         (lptr_t)(Bs + ((c & 1) * 3 + p) * CF::PIECE + rbk * 512), 16, 0, 0);
+    }
+  };
+  auto dma_a = [&](int c) {
+    if (c >= nch) return;
+    int ct, kA; bool f, l;
+    decode(c, ct, kA, f, l);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbk = wave + 4 * i;
+      int64_t row = m0 + rbk * 16 + drow;
+      row = row < g.nrows ? row : 0;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Wh + p * g.w_stride + row * Mp + kA + dq),
+                                         (lptr_t)(As + ((c & 1) * 3 + p) * CF::PIECE + rbk * 512), 16, 0, 0);
+    }
+  };
+  float rs[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[a][r] = 0;
+  f32x4 acc[4][4];
+  const int frag = lr * 32 + ((lg ^ bf16x6_swz(lr)) << 3);
+  auto mult = [&](int c) {
+    int ct, kA; bool first, last;
+    decode(c, ct, kA, first, last);
+    if (first) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+    }
+    const __bf16* Ab = As + (c & 1) * IMG;
+    const __bf16* Bb = Bs + (c & 1) * IMG;
+    bf16x8 fb[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const bf16x8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+    bf16x8 faq[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) faq[0][p] = *reinterpret_cast<const bf16x8*>(Ab + p * CF::PIECE + (wr * 64) * 32 + frag);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      bf16x8 (&fa)[3] = faq[a & 1];
+      if (a + 1 < 4) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) faq[(a + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(Ab + p * CF::PIECE + (wr * 64 + (a + 1) * 16) * 32 + frag);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][b], acc[a][b], 0, 0, 0);
+    }
+    if (last) {                                                 // fold the finished column tile into the row sums
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool cok = ct * GDRF_TILE + wc * 64 + b * 16 + lr < Mp;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rs[a][r] += cok ? acc[a][b][r] * acc[a][b][r] : 0.0f;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto phase_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  dma_a(0);
+  if (gp == 0) dma_a(1); else dma_b(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  phase_barrier();
+  for (int ph = 0; ph < 2 * nch; ++ph) {
+    const int t = ph >> 1;
+    if ((ph & 1) == gp) {
+      mult(t);
+    } else if (gp == 0) {
+      dma_a(t + 2);                        // phase 2t+1: buffer (t+2)&1 was last read in phase 2t
+    } else {
+      dma_a(t + 1);                        // phase 2t: own buffer (t+1)&1 last read in phase 2t-1; so was the shared B buffer
+      dma_b(t + 1);
+    }
+    phase_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // row sums: 16-lane groups, then the two waves of a group that share the rows, through LDS
+  float* rsum = reinterpret_cast<float*>(smem) + gp * GDRF_TILE;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[a][r] = group16_sum(rs[a][r]);
+  __syncthreads();
+  if (wc == 0 && lr == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rsum[wr * 64 + a * 16 + lg * 4 + r] = rs[a][r];
+  }
+  __syncthreads();
+  if (wc == 1 && lr == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rsum[wr * 64 + a * 16 + lg * 4 + r] += rs[a][r];
+  }
+  __syncthreads();
+  if (tid < GDRF_TILE) {
+    const int64_t m = m0 + tid;
+    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = rsum[tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // TN form (reduction over observations):  C[i][j] = sum_n A[n][i] * s[n] * B[n][j]  on the same emulation; replaces
 // gemm_tn_kernel<float> for A_k = W^T diag(vbar_k) W (sym) and GT = W^T Wbar.  A comes pre-split (Wh), B is f32 and is
 // scaled by s[n] and split when it is staged (the scale runs along the reduction index, so it cannot be pulled out of the
