@@ -479,7 +479,7 @@ template <typename T, typename TS> struct Impl {
                        int nbatch, int ns, int ntiles, hipStream_t s) {
     if constexpr (std::is_same<T, float>::value) {
       TNBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns};
-      constexpr int lds = 2 * 3 * 32 * 128 * 2;
+      constexpr int lds = 3 * 3 * 32 * 128 * 2;                 // double-buffered A image + B image
       HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(gemm_tn_bf16x6_kernel, dim3((unsigned)(ntiles * nbatch * ns)), dim3(256), lds, s, a);
       return 0;

@@ -673,11 +673,13 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
 // product).  Both operands are staged as they lie in memory (n-major rows) and the MFMA fragments (8 consecutive n per lane)
 // are gathered with the transposing LDS read ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
 //
-// LDS piece image of a 32 (n) x 128 (column) chunk, in 8-byte segments of 4 columns:  segment (k, c4) lives at
-//   seg(k, c4) = ((((k >> 2) * 32 + c4) << 2) | (k & 3)) ^ (((k >> 3) & 1) << 4)
-// A transposed read of one half-wave touches, for quads lg in {0,1} (or {2,3}), the 32 segments (k = 8 lg + 4 h + q, c4 =
-// base + p), q, p = 0..3: 4 p + q spans 16 consecutive segments and the XOR sends the odd quad to the other 16 -> 32 distinct
-// 8-byte bank pairs, conflict-free.
+// LDS piece image of a 32 (n) x 128 (column) chunk: row-major (256-byte rows, so an LDS-DMA instruction fills 4 whole rows
+// from the row-major pieces), with the 8-byte column quad c4 XOR-swizzled by the row:
+//   seg(k, c4) = k * 32 + (c4 ^ (code(k) << 2)),  code(k) = ((k >> 3) & 1) << 2 | (k & 3)      (8-byte segments)
+// A transposing fragment read of a half-wave touches rows k = 8 lg + 4 h + q (lg in {0,1} or {2,3}, q = 0..3) x quads base + p,
+// p = 0..3: the eight (lg & 1, q) codes send the eight rows to eight different 32-byte groups of the 256-byte bank window -
+// conflict-free.  The pre-split A operand is staged by DMA (double-buffered, no registers, no LDS stores); the B operand, which
+// must be scaled and split, goes through registers and 12 ds_write_b64 per thread.
 struct TNBf16Args {
   const __bf16* Ah; int64_t a_stride; int64_t lda;     // pieces [p][n][lda]
   const float* B; int64_t ldb;                         // [n][ldb]
@@ -688,13 +690,14 @@ struct TNBf16Args {
   int nbatch, nsplit;
 };
 
-__device__ __forceinline__ int tnb_seg(int k, int c4) { return ((((k >> 2) * 32 + c4) << 2) | (k & 3)) ^ (((k >> 3) & 1) << 4); }
+__device__ __forceinline__ int tnb_code(int k) { return (((k >> 3) & 1) << 2) | (k & 3); }
+__device__ __forceinline__ int tnb_seg(int k, int c4) { return k * 32 + (c4 ^ (tnb_code(k) << 2)); }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
   constexpr int PIECE = 32 * 128;             // halfwords per piece image (8 KB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem);
-  __bf16* Bs = As + 3 * PIECE;
+  __bf16* As = reinterpret_cast<__bf16*>(smem);           // [2 buffers][3][32][128]
+  __bf16* Bs = As + 6 * PIECE;                             // [3][32][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   const int nt = (g.ncols + GDRF_TILE - 1) / GDRF_TILE;
@@ -729,27 +732,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0, 0, 0, 0};
 
-  // staging maps.  A: vector of 8 columns (q = tid&3 -> row 4*(khi + 4 i) + q, c8 = (tid>>2)&15, khi = tid>>6), 2 per piece.
-  // B: f32x4 of 4 columns (q = tid&3 -> row 4*(khi + 2 i) + q, c4 = (tid>>2)&31, khi = tid>>7), 4 per thread.
-  const int sq = tid & 3;
-  const int a_c8 = (tid >> 2) & 15, a_kh = tid >> 6;
-  const int b_c4 = (tid >> 2) & 31, b_kh = tid >> 7;
-  const bool a_ok = (i0 + a_c8 * 8) < g.ncols, b_ok = (j0 + b_c4 * 4) < g.ncols;     // ncols multiple of 32
-  bf16x8 ra[3][2];
-  f32x4 rb[4];
-  float rs[4];
-  auto gload = [&](int64_t rbase) {
+  // A: DMA, 4 rows (1 KB) per instruction: lane l -> row l>>4, physical 16-byte unit l&15 = logical unit (l&15) ^ (code << 1);
+  // this wave moves row blocks wave and wave + 4 of every piece.  Rows past the split / the end meet a zero B row; columns past
+  // the end give rows of C that are never stored.
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nch = r0 < r1 ? (int)((r1 - r0 + 31) / 32) : 0;
+  auto dma_a = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int64_t n = rbase + 4 * (a_kh + 4 * i) + sq;
-      const bool ok = a_ok && n < r1;
-      const int64_t off = (ok ? n : r0) * g.lda + (a_ok ? i0 + a_c8 * 8 : 0);
+      const int blk = wave + 4 * i, k = 4 * blk + (lane >> 4);
+      const int c8 = (lane & 15) ^ (tnb_code(k) << 1);
+      int64_t n = r0 + (int64_t)c * 32 + k;
+      n = n < g.nrows ? n : g.nrows - 1;
+      const int col = (i0 + c8 * 8 < g.ncols) ? i0 + c8 * 8 : 0;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(g.Ah + p * g.a_stride + off);
-        ra[p][i] = __builtin_bit_cast(bf16x8, ok ? raw : u32x4{0, 0, 0, 0});
-      }
+      for (int p = 0; p < 3; ++p)
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Ah + p * g.a_stride + n * g.lda + col),
+                                         (lptr_t)(As + ((c & 1) * 3 + p) * PIECE + blk * 512), 16, 0, 0);
     }
+  };
+  // B: f32x4 of 4 columns (q = tid&3 -> row 4*(khi + 2 i) + q, c4 = (tid>>2)&31, khi = tid>>7), 4 per thread
+  const int sq = tid & 3, b_c4 = (tid >> 2) & 31, b_kh = tid >> 7;
+  const bool b_ok = (j0 + b_c4 * 4) < g.ncols;                // ncols multiple of 32
+  f32x4 rb[4];
+  float rs[4];
+  auto load_b = [&](int c) {
+    const int64_t rbase = r0 + (int64_t)c * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t n = rbase + 4 * (b_kh + 2 * i) + sq;
@@ -759,20 +768,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
       rs[i] = (sc && ok) ? sc[n] : 1.0f;
     }
   };
-  // fragment read bases (8-byte segments): k = 8 lg + 4 h + q, c4 = 16 w + 4 t + p with q = (lane&15)>>2, p = lane&3; the
-  // XOR of the image flips the parity of t for the odd quads: seg = base + 128 h + 16 (t ^ (lg & 1))
-  const int fq = lr >> 2, fp = lr & 3, fm = lg & 1;
-  const int a_base = ((((2 * lg) * 32 + 16 * wr + fp) << 2) | fq);
-  const int b_base = ((((2 * lg) * 32 + 16 * wc + fp) << 2) | fq);
-  auto frag = [&](const __bf16* img, int base, int t) -> bf16x8 {
-    const int s0 = base + 16 * (t ^ fm);
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + s0 * 4));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + (s0 + 128) * 4));
+  // fragments: two transposing reads (k = 8 lg + q and + 4) of 4 rows x 16 columns each; seg = (8 lg + 4 h + q) * 32 + ((4 w + t) ^ code) * 4 + p
+  const int fq = lr >> 2, fp = lr & 3, fcode = ((lg & 1) << 2) | fq;
+  const int fbase = (8 * lg + fq) * 32 + fp;
+  int xa[4], xb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { xa[t] = fbase + (((4 * wr + t) ^ fcode) << 2); xb[t] = fbase + (((4 * wc + t) ^ fcode) << 2); }
+  auto frag = [&](const __bf16* img, int seg) -> bf16x8 {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + seg * 4));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + (seg + 128) * 4));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
-  if (r0 < r1) gload(r0);
-  for (int64_t r = r0; r < r1; r += 32) {
+  if (nch > 0) { dma_a(0); load_b(0); }
+  for (int c = 0; c < nch; ++c) {
     // scale and split the prefetched B vectors BEFORE the barrier: the conversion then overlaps the other waves' MFMAs
     // instead of sitting in the barrier-to-barrier staging section
     bf16x4 hb[4], mb[4], lb[4];
@@ -780,17 +789,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { __bf16 x1, x2, x3; split3(rb[i][e] * rs[i], x1, x2, x3); hb[i][e] = x1; mb[i][e] = x2; lb[i][e] = x3; }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = 4 * (a_kh + 4 * i) + sq;
-      const int s0 = tnb_seg(k, 2 * a_c8) * 4, s1 = tnb_seg(k, 2 * a_c8 + 1) * 4;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        *reinterpret_cast<bf16x4*>(As + p * PIECE + s0) = __builtin_shufflevector(ra[p][i], ra[p][i], 0, 1, 2, 3);
-        *reinterpret_cast<bf16x4*>(As + p * PIECE + s1) = __builtin_shufflevector(ra[p][i], ra[p][i], 4, 5, 6, 7);
-      }
-    }
+    __syncthreads();                       // (its vmcnt(0) also retires this wave's DMA of chunk c, issued one iteration ago)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int so = tnb_seg(4 * (b_kh + 2 * i) + sq, b_c4) * 4;
@@ -799,29 +798,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
       *reinterpret_cast<bf16x4*>(Bs + 2 * PIECE + so) = lb[i];
     }
     __syncthreads();
-    if (r + 32 < r1) gload(r + 32);
+    if (c + 1 < nch) { dma_a(c + 1); load_b(c + 1); }          // A buffer (c+1)&1 was last read in iteration c-1
+    const __bf16* Ab = As + (c & 1) * 3 * PIECE;
     bf16x8 fb[3][4];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) fb[p][c] = frag(Bs + p * PIECE, b_base, c);
+      for (int t = 0; t < 4; ++t) fb[p][t] = frag(Bs + p * PIECE, xb[t]);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       bf16x8 fa[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[p] = frag(As + p * PIECE, a_base, a);
+      for (int p = 0; p < 3; ++p) fa[p] = frag(Ab + p * PIECE, xa[a]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2][c], acc[a][c], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2][t], acc[a][t], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1][c], acc[a][c], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1][t], acc[a][t], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0][c], acc[a][c], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0][t], acc[a][t], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1][c], acc[a][c], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1][t], acc[a][t], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0][c], acc[a][c], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0][t], acc[a][t], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][c], acc[a][c], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][t], acc[a][t], 0, 0, 0);
     }
   }
   float* out = g.slab + ((int64_t)sp * g.nbatch + b) * (int64_t)g.ncols * g.ncols;
