@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
 // A transposing fragment read of a half-wave touches rows k = 8 lg + 4 h + q (lg in {0,1} or {2,3}, q = 0..3) x quads base + p,
 // p = 0..3: the eight (lg & 1, q) codes send the eight rows to eight different 32-byte groups of the 256-byte bank window -
 // conflict-free.  The pre-split A operand is staged by DMA (double-buffered, no registers, no LDS stores); the B operand, which
-// must be scaled and split, goes through registers and 12 ds_write_b64 per thread.
+// must be scaled and split, goes through registers and 6 ds_write_b128 per thread.
 struct TNBf16Args {
   const __bf16* Ah; int64_t a_stride; int64_t lda;     // pieces [p][n][lda]
   const float* B; int64_t ldb;                         // [n][ldb]
@@ -752,19 +752,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
                                          (lptr_t)(As + ((c & 1) * 3 + p) * PIECE + blk * 512), 16, 0, 0);
     }
   };
-  // B: f32x4 of 4 columns (q = tid&3 -> row 4*(khi + 2 i) + q, c4 = (tid>>2)&31, khi = tid>>7), 4 per thread
-  const int sq = tid & 3, b_c4 = (tid >> 2) & 31, b_kh = tid >> 7;
-  const bool b_ok = (j0 + b_c4 * 4) < g.ncols;                // ncols multiple of 32
-  f32x4 rb[4];
-  float rs[4];
+  // B: 8 columns of a row per vector pair (q = tid&3 -> row 4*(khi + 4 i) + q, c8 = (tid>>2)&15, khi = tid>>6), 2 rows per thread:
+  // two adjacent f32x4 loads, and after the split ONE ds_write_b128 per piece (the swizzle keeps the quads 2 c8, 2 c8 + 1 adjacent)
+  const int sq = tid & 3, b_c8 = (tid >> 2) & 15, b_kh = tid >> 6;
+  const bool b_ok = (j0 + b_c8 * 8) < g.ncols;                // ncols multiple of 32
+  f32x4 rb[4];                                                 // [2 i + half]
+  float rs[2];
   auto load_b = [&](int c) {
     const int64_t rbase = r0 + (int64_t)c * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t n = rbase + 4 * (b_kh + 2 * i) + sq;
+    for (int i = 0; i < 2; ++i) {
+      const int64_t n = rbase + 4 * (b_kh + 4 * i) + sq;
       const bool ok = b_ok && n < r1;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(g.B + (ok ? n : r0) * g.ldb + (b_ok ? j0 + b_c4 * 4 : 0));
-      rb[i] = ok ? v : f32x4{0, 0, 0, 0};
+      const float* src = g.B + (ok ? n : r0) * g.ldb + (b_ok ? j0 + b_c8 * 8 : 0);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+      rb[2 * i] = ok ? v0 : f32x4{0, 0, 0, 0};
+      rb[2 * i + 1] = ok ? v1 : f32x4{0, 0, 0, 0};
       rs[i] = (sc && ok) ? sc[n] : 1.0f;
     }
   };
@@ -784,18 +787,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
   for (int c = 0; c < nch; ++c) {
     // scale and split the prefetched B vectors BEFORE the barrier: the conversion then overlaps the other waves' MFMAs
     // instead of sitting in the barrier-to-barrier staging section
-    bf16x4 hb[4], mb[4], lb[4];
+    bf16x8 hb[2], mb[2], lb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 x1, x2, x3; split3(rb[i][e] * rs[i], x1, x2, x3); hb[i][e] = x1; mb[i][e] = x2; lb[i][e] = x3; }
+      for (int e = 0; e < 8; ++e) {
+        __bf16 x1, x2, x3;
+        split3(rb[2 * i + (e >> 2)][e & 3] * rs[i], x1, x2, x3);
+        hb[i][e] = x1; mb[i][e] = x2; lb[i][e] = x3;
+      }
     __syncthreads();                       // (its vmcnt(0) also retires this wave's DMA of chunk c, issued one iteration ago)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int so = tnb_seg(4 * (b_kh + 2 * i) + sq, b_c4) * 4;
-      *reinterpret_cast<bf16x4*>(Bs + so) = hb[i];
-      *reinterpret_cast<bf16x4*>(Bs + PIECE + so) = mb[i];
-      *reinterpret_cast<bf16x4*>(Bs + 2 * PIECE + so) = lb[i];
+    for (int i = 0; i < 2; ++i) {
+      const int so = tnb_seg(4 * (b_kh + 4 * i) + sq, 2 * b_c8) * 4;
+      *reinterpret_cast<bf16x8*>(Bs + so) = hb[i];
+      *reinterpret_cast<bf16x8*>(Bs + PIECE + so) = mb[i];
+      *reinterpret_cast<bf16x8*>(Bs + 2 * PIECE + so) = lb[i];
     }
     __syncthreads();
     if (c + 1 < nch) { dma_a(c + 1); load_b(c + 1); }          // A buffer (c+1)&1 was last read in iteration c-1
