@@ -131,6 +131,60 @@ def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
     assert (r0["params"] - model._engine.params.cpu()).abs().max() < 1e-9
 
 
+def _build_lz_renyi(dtype=torch.float64):
+    """Learnable inducing inputs + RenyiELBO(alpha=0.5, 2 particles): the payload entries only those options add."""
+    from gdrf_amd import poutine
+    from gdrf_amd.infer import SVI, OBJECTIVE_DICT
+    from gdrf_amd.kernels import KERNEL_DICT
+    from gdrf_amd.models import GDRF_MODEL_DICT
+    from gdrf_amd.optim import OPTIMIZER_DICT
+    xs_np, ws_np, _ = synth_circles(30, 20, 12, 3, seed=5)
+    device = "cuda:0"
+    xs, ws = torch.from_numpy(xs_np).to(device=device, dtype=dtype), torch.from_numpy(ws_np).int().to(device)
+    kern = KERNEL_DICT["rbf"](input_dim=2, lengthscale=torch.tensor(0.2), variance=torch.tensor(25.0)).to(device)
+    model = GDRF_MODEL_DICT["sparsemultinomialgdrf"](
+        xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=kern, num_observation_categories=12, device=device, num_topic_categories=3,
+        dirichlet_param=0.01, n_points=[5, 4], fixed_inducing_points=False, inducing_init="random", maxjitter=15, jitter=1e-6,
+        dtype=dtype, seed=5)
+    svi = SVI(model=poutine.scale(scale=1.0 / len(xs))(model.model), guide=poutine.scale(scale=1.0 / len(xs))(model.guide),
+              optim=OPTIMIZER_DICT["adam"]({"lr": 0.02}),
+              loss=OBJECTIVE_DICT["renyielbo"](max_plate_nesting=1, vectorize_particles=True, num_particles=2, alpha=0.5))
+    return model, svi, xs, ws
+
+
+def _dist_worker_lz(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, svi, xs, ws = _build_lz_renyi()
+    N = len(xs)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    svi.row_offset = lo
+    losses = [svi.step(xs=xs[lo:hi], ws=ws[lo:hi], subsample=False) for _ in range(3)]
+    torch.save({"losses": losses, "params": model._engine.params.cpu()}, os.path.join(tmp, f"lz{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_learnable_inducing_points_and_renyi_match_a_single_rank(tmp_path):
+    """The all-reduced payload also carries the inducing-input sums, and RenyiELBO's particle weights need the particles' ELBO
+    over ALL ranks: two ranks (gloo, one GPU) must reproduce the single-rank losses and parameters."""
+    import torch.multiprocessing as mp
+    port = 31600 + (os.getpid() % 2000)
+    mp.spawn(_dist_worker_lz, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    model, svi, xs, ws = _build_lz_renyi()
+    ref = [svi.step(xs=xs, ws=ws, subsample=False) for _ in range(3)]
+    r0 = torch.load(tmp_path / "lz0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "lz1.pt", weights_only=True)
+    assert r0["losses"] == r1["losses"] and torch.equal(r0["params"], r1["params"])
+    assert np.allclose(r0["losses"], ref, rtol=1e-9)
+    assert (r0["params"] - model._engine.params.cpu()).abs().max() < 1e-8
+    zoff = model._engine.layout["inducing_unc"]
+    assert (r0["params"][zoff:zoff + 40] - model._engine.params.cpu()[zoff:zoff + 40]).abs().max() < 1e-8
+
+
 def test_train_driver_full_batch_and_streaming():
     from gdrf_amd.train import train
     xs, ws, _ = synth_circles(24, 16, 20, 4, seed=2)
