@@ -10,7 +10,7 @@
 //
 //   split3_kernel            W, B_k = S_k S_k^T and S_k^T -> 3 bf16 pieces each, once per step
 //   bwd_wbar_bf16x6_kernel   Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W   (replaces gemm_nt<BwdWbarProb>)
-//   fwd_t_bf16x6_kernel      tt[k][n] = |S_k^T w_n|^2                                           (replaces gemm_nt<FwdTProb>)
+//   fwd_t_bf16x6_2g_kernel   tt[k][n] = |S_k^T w_n|^2                                           (replaces gemm_nt<FwdTProb>)
 //   gemm_tn_bf16x6_kernel    A_k = W^T diag(vbar_k) W  and  GT = W^T Wbar                        (replaces gemm_tn_kernel<float>)
 //
 // All keep the tiling, block maps, deterministic slab reduction and epilogues of the f32 forms they replace.
@@ -369,128 +369,14 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// tt[k][n] = || S_k^T w_n ||^2 on the same emulation: T_k = W S_k lives only in the accumulators.  One workgroup per
-// (row tile, topic) walks the column tiles (triangular k range i >= j), as gemm_nt<FwdTProb> does.
+// tt[k][n] = || S_k^T w_n ||^2 on the same emulation: T_k = W S_k lives only in the accumulators; a row tile and topic walk
+// the column tiles (triangular k range i >= j), as gemm_nt<FwdTProb> does.
 struct FwdTBf16Args {
   const __bf16* Wh; int64_t w_stride; int64_t nrows; int Mp, K;
-  int KG; int rt8;                            // topics per group (see the block map), ceil(row tiles / 8)
+  int KG; int rt8;                            // topics per group (see the block map), ceil(row-tile pairs / 8)
   const __bf16* STh; int64_t piece_stride;    // STh[p][k][i / 32][j][i % 32] = pieces of S_k[i][j] (k-blocked)
   float* tt; int64_t ldt;
 };
-
-__global__ __launch_bounds__(256, 2) void fwd_t_bf16x6_kernel(FwdTBf16Args g) {
-  using CF = Bf16x6Cfg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem);
-  __bf16* Bs = As + 3 * CF::PIECE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
-  const int Mp = g.Mp;
-  const int nct = (Mp + GDRF_TILE - 1) / GDRF_TILE;
-  // block map: XCD = blockIdx & 7 owns row tiles r*8 + xcd.  Topics go in groups of KG, group-major: every XCD first runs
-  // all its row tiles for topics [0, KG), then for [KG, 2KG), ...  so that only KG topics' S^T pieces (KG x ~1 MB at M=512)
-  // are live in its 4 MB L2 at a time; the KG workgroups of one row tile are adjacent and share its W slab there.
-  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-  const unsigned per_group = (unsigned)g.KG * (unsigned)g.rt8;
-  const int grp = (int)(idx / per_group);
-  const unsigned rem = idx - (unsigned)grp * per_group;
-  const int kg = min(g.KG, g.K - grp * g.KG);
-  const int64_t rtile = (int64_t)(rem / (unsigned)kg) * 8 + xcd;
-  const int bz = grp * g.KG + (int)(rem % (unsigned)kg);
-  const int64_t m0 = rtile * GDRF_TILE;
-  float rs[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rs[a][r] = 0;
-  const int frag = lr * 32 + ((lg ^ bf16x6_swz(lr)) << 3);      // this lane's fragment offset inside a 16-row group
-
-  bf16x8 ra[3][2], rb[3][2];
-  for (int ct = 0; ct < nct; ++ct) {
-    const int n0 = ct * GDRF_TILE;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
-    auto gload = [&](int kA) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int v = tid + 256 * j, kq = (v & 3) * 8, rr = v >> 2;
-        int64_t row = m0 + rr;
-        row = row < g.nrows ? row : 0;        // rows past the end read row 0; their tt entries are never stored
-        const bool cok = n0 + rr < Mp;        // columns >= Mp must contribute 0 to the row sums
-        const int col = cok ? n0 + rr : 0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          ra[p][j] = *reinterpret_cast<const bf16x8*>(g.Wh + p * g.w_stride + row * Mp + kA + kq);
-          const u32x4 raw = *reinterpret_cast<const u32x4*>(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + kq);
-          const u32x4 msk = cok ? raw : u32x4{0, 0, 0, 0};
-          rb[p][j] = __builtin_bit_cast(bf16x8, msk);
-        }
-      }
-    };
-    const int kb = n0, ke = Mp;
-    if (kb < ke) gload(kb);
-    for (int kA = kb; kA < ke; kA += CF::BK) {
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int v = tid + 256 * j, off = bf16x6_off(v >> 2, (v & 3) * 8);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          *reinterpret_cast<bf16x8*>(As + p * CF::PIECE + off) = ra[p][j];
-          *reinterpret_cast<bf16x8*>(Bs + p * CF::PIECE + off) = rb[p][j];
-        }
-      }
-      __syncthreads();
-      if (kA + CF::BK < ke) gload(kA + CF::BK);
-      bf16x8 fb[3][4];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const bf16x8*>(Bs + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
-      bf16x8 faq[2][3];                    // the next row group's fragments are read while this one multiplies
-#pragma unroll
-      for (int p = 0; p < 3; ++p) faq[0][p] = *reinterpret_cast<const bf16x8*>(As + p * CF::PIECE + (wr * 64) * 32 + frag);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        bf16x8 (&fa)[3] = faq[a & 1];
-        if (a + 1 < 4) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            faq[(a + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(As + p * CF::PIECE + (wr * 64 + (a + 1) * 16) * 32 + frag);
-        }
-        // six cross products, small terms first, straight into the tile accumulator (no per-row factor here): 6 roundings
-        // of the accumulator per 32 reduction indices, fewer than the 8 of the native 16x16x4 f32 form
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][b], acc[a][b], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rs[a][r] += acc[a][b][r] * acc[a][b][r];
-  }
-  float* rsum = reinterpret_cast<float*>(smem);
-  nt_rowsum_finish<float>(rs, rsum, wr, wc, lane);
-  if (tid < GDRF_TILE) {
-    const int64_t m = m0 + tid;
-    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = rsum[tid];
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // tt in the two-group LDS-DMA structure of bwd_wbar_bf16x6_kernel<2>: a 512-thread workgroup holds two adjacent row tiles of
@@ -498,7 +384,9 @@ __global__ __launch_bounds__(256, 2) void fwd_t_bf16x6_kernel(FwdTBf16Args g) {
 // (by group 1) into a double-buffered image both read, and every group double-buffers its own W chunk.  Chunk c is multiplied
 // by group 0 in phase 2c and by group 1 in phase 2c+1; DMAs are issued in a group's idle phase two chunks ahead (group 0) / one
 // chunk ahead (group 1), land during its next multiply phase and are retired by the vmcnt(0) that ends it.
-// Grid: 8 * K * rt8 with rt8 = ceil(row-tile pairs / 8); block map as fwd_t_bf16x6_kernel with pairs for row tiles.
+// Grid: 8 * K * rt8 with rt8 = ceil(row-tile pairs / 8).  Block map: XCD = blockIdx & 7 owns the pairs r * 8 + xcd; topics go
+// in groups of KG, group-major (every XCD first runs all its pairs for topics [0, KG), then [KG, 2 KG), ...) so that only KG
+// topics' S^T pieces (~1 MB each at M = 512) are live in its 4 MB L2 at a time; the KG workgroups of one pair are adjacent.
 __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g) {
   using CF = Bf16x6Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
