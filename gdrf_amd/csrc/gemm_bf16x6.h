@@ -99,7 +99,7 @@ template <int NG>
 __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args g) {
   using CF = Bf16x6Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int gp = NG == 2 ? (int)(threadIdx.x >> 8) : 0;
+  const int gp = NG == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
   // LDS: NG = 1: [A][B][scale];  NG = 2: [A of group 0][A of group 1][B buffer 0][B buffer 1][scale 0][scale 1] - the two
   // groups work on the same column tile, so the B chunk is staged ONCE (by group 1) into a double-buffered image both read
   constexpr int IMG = 3 * CF::PIECE;                          // halfwords per operand image
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
     // 16-row block of one piece image, 1 KB: lane l lands at block + 16 l = row l>>2, physical quad l&3, so its SOURCE is
     // logical quad (l&3) ^ swz(row) - the image swizzle goes on the global address (cdna_hip_programming.md 5.4 rule 21).
     const int drow = lane >> 2, dq = ((lane & 3) ^ bf16x6_swz(drow)) * 8;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto dma_b = [&](int c) {             // B chunk c -> buffer c & 1; this wave moves row blocks wave and wave + 4 of each piece
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
       const int q = c / K, rep = c - q * K;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int rbk = wave + 4 * i, row = rbk * 16 + drow;
+        const int rbk = wave_u + 4 * i, row = rbk * 16 + drow;
         const int col = (n0 + row < Mp) ? n0 + row : 0;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
       if (q >= nk) return;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int rbk = wave + 4 * i;
+        const int rbk = wave_u + 4 * i;
         int64_t row = m0 + rbk * 16 + drow;
         row = row < g.nrows ? row : 0;
 #pragma unroll
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
   using CF = Bf16x6Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int IMG = 3 * CF::PIECE;                          // halfwords per operand image
-  const int gp = (int)(threadIdx.x >> 8);
+  const int gp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   __bf16* As = reinterpret_cast<__bf16*>(smem) + gp * 2 * IMG;      // [2 buffers][3][128][32] of this group
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
     }
   };
   const int drow = lane >> 2, dq = ((lane & 3) ^ bf16x6_swz(drow)) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto dma_b = [&](int c) {
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
     decode(c, ct, kA, f, l);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int rbk = wave + 4 * i, row = rbk * 16 + drow;
+      const int rbk = wave_u + 4 * i, row = rbk * 16 + drow;
       const int col = (ct * GDRF_TILE + row < Mp) ? ct * GDRF_TILE + row : 0;      // columns >= Mp are skipped when the tile is folded
 #pragma unroll
       for (int p = 0; p < 3; ++p)
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
     decode(c, ct, kA, f, l);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int rbk = wave + 4 * i;
+      const int rbk = wave_u + 4 * i;
       int64_t row = m0 + rbk * 16 + drow;
       row = row < g.nrows ? row : 0;
 #pragma unroll
@@ -623,13 +625,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
   // A: DMA, 4 rows (1 KB) per instruction: lane l -> row l>>4, physical 16-byte unit l&15 = logical unit (l&15) ^ (code << 1);
   // this wave moves row blocks wave and wave + 4 of every piece.  Rows past the split / the end meet a zero B row; columns past
   // the end give rows of C that are never stored.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int nch = r0 < r1 ? (int)((r1 - r0 + 31) / 32) : 0;
   auto dma_a = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int blk = wave + 4 * i, k = 4 * blk + (lane >> 4);
+      const int blk = wave_u + 4 * i, k = 4 * blk + (lane >> 4);
       const int c8 = (lane & 15) ^ (tnb_code(k) << 1);
       int64_t n = r0 + (int64_t)c * 32 + k;
       n = n < g.nrows ? n : g.nrows - 1;
