@@ -453,8 +453,9 @@ template <typename T, typename TS> struct Impl {
       {
         ScopedTimer tm(c, 2, s);
         hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->ST, nb, Mp, Mp, (__bf16*)c->STh, nb);
-        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nw / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->W, nw, (__bf16*)c->Wh,
-                           (int64_t)c->ncap * Mp);
+        if (c->ssz != 8)       // with the f64 solve, fwd_w's epilogue has already written the pieces of W
+          hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nw / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->W, nw, (__bf16*)c->Wh,
+                             (int64_t)c->ncap * Mp);
       }
       ScopedTimer tm(c, 5, s);
       // topics per group: as many lower-triangular S^T piece panels (3 x ~0.6 Mp^2 halfwords each) as fit in 2 MB
@@ -570,6 +571,7 @@ template <typename T, typename TS> struct Impl {
       if ((rc = join_fact(c, s))) return rc;          // W needs L^-1
       ScopedTimer tm(c, 3, s);
       FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
+      if (c->bf16x6 && sizeof(TS) == 8 && sizeof(T) == 4) { p.Wh = (__bf16*)c->Wh; p.wh_stride = (int64_t)c->ncap * Mp; }   // pieces of W from the same epilogue
       hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
     }
     // loc = W U^T, on the side stream beside fwd_t (both only read W)

@@ -168,6 +168,7 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
   static constexpr int DEPTH = 1;
   const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
+  __bf16* Wh = nullptr; int64_t wh_stride = 0;        // optional: the 3 bf16 pieces of W (gemm_bf16x6.h), written by the same epilogue
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx { T rs[4][4]; int ct; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
@@ -203,11 +204,63 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < NTCfg<T>::NB; ++b) ec.rs[a][r] += acc[a][b][r] * acc[a][b][r];
+    if constexpr (sizeof(T) == 8 && sizeof(TN) == 4) {
+      if (Wh) {
+        // f64 solve, f32 W, bf16x6 contractions: each wave transposes its 64 x 32 quadrant through a private LDS tile, 32 rows
+        // at a time, and stores whole 128-byte row segments - W as float4 and its three bf16 pieces as 8-byte vectors - instead
+        // of 32 scalar stores per lane followed by a separate pass that re-reads all of W to split it.
+        extern __shared__ __attribute__((aligned(16))) char nt_smem[];
+        constexpr int TS_ = 36;                               // tile row stride in floats (144 B)
+        float* tile = reinterpret_cast<float*>(nt_smem) + (threadIdx.x >> 6) * (32 * TS_);
+        const int lr = lane & 15, lg = lane >> 4;
+        __syncthreads();                                      // every wave is done with the operand images of the last chunk
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b = 0; b < NTCfg<T>::NB; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tile[(a2 * 16 + lg + 4 * r) * TS_ + b * 16 + lr] = (float)acc[2 * h + a2][b][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave writes and reads: LDS is in order per wave
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rr = (lane >> 3) + 8 * i, cv = (lane & 7) * 4;
+            const int64_t m = m0 + wr * 64 + h * 32 + rr;
+            const int n = n0 + wc * (NTCfg<T>::CW / 2) + cv;
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            const f4 t = *reinterpret_cast<const f4*>(tile + rr * TS_ + cv);
+            if (m < nrows && n < Mp) {                        // Mp is a multiple of 32: a vector never straddles the edge
+              *reinterpret_cast<f4*>(W + m * Mp + n) = t;
+              b4 ph, pm, pl;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const __bf16 x1 = (__bf16)t[e];
+                const float r1 = t[e] - (float)x1;
+                const __bf16 x2 = (__bf16)r1;
+                ph[e] = x1; pm[e] = x2; pl[e] = (__bf16)(r1 - (float)x2);
+              }
+              *reinterpret_cast<b4*>(Wh + m * Mp + n) = ph;
+              *reinterpret_cast<b4*>(Wh + wh_stride + m * Mp + n) = pm;
+              *reinterpret_cast<b4*>(Wh + 2 * wh_stride + m * Mp + n) = pl;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + nt_acc_row<T>(wr, a, lane, r);
 #pragma unroll
         for (int b = 0; b < NTCfg<T>::NB; ++b) {
-          ec.rs[a][r] += acc[a][b][r] * acc[a][b][r];
           const int n = n0 + nt_acc_col<T>(wc, b, lane);
           if (m < nrows && n < Mp) W[m * Mp + n] = (TN)acc[a][b][r];
         }
