@@ -210,6 +210,8 @@ def main():
         dom_t = ms[dom] * 1e-3
         ach = flops[dom] / dom_t / 1e12 if dom_t > 0 else 0.0
         peak = PEAK_F32_MFMA_TFLOPS if dtype == torch.float32 else PEAK_F32_MFMA_TFLOPS / 2
+        if dom in ("fwd_w", "bwd_knm") and not eng.pure_fp32:
+            peak = PEAK_F32_MFMA_TFLOPS / 2          # the solve-side GEMMs run on f64 MFMA in every mode but the all-fp32 one
         emulated = eng.mfma_mode == "bf16x6" and dom in ("fwd_t", "bwd_wbar", "tn_sym", "tn_gt")
         if emulated:     # six bf16 MFMA products per f32 multiply-add (csrc/gemm_bf16x6.h); tiles are computed whole
             issued = {"fwd_t": 1.25, "bwd_wbar": 1.0, "tn_sym": 1.25, "tn_gt": 1.0}[dom] * 6.0 * ach
