@@ -464,3 +464,43 @@ def test_three_dimensional_world_with_learnable_inducing_points():
     for name in eng.param_names:
         got, ref = eng.view(name, eng.grads).cpu().numpy(), grads[name].numpy()
         assert np.abs(got - ref).max() < 1e-8 * max(np.abs(ref).max(), 1e-6), name
+
+
+# ---- odd shapes through the default fp32 build (bf16x6 kernels, two-group forms, DMA staging) -------------------------------
+ODD_SHAPES = [
+    dict(W=13, H=10, V=7, K=1, n_points=(3, 3)),           # K = 1: bwd_wbar's single-group fallback; N = 130: a padded second row tile
+    dict(W=3, H=2, V=5, K=3, n_points=(4, 2)),             # six observations: far less than one row tile
+    dict(W=43, H=3, V=9, K=2, n_points=(7, 5)),            # M = 35 -> Mp = 64, N = 129
+    dict(W=30, H=20, V=11, K=17, n_points=(13, 10)),       # K = 17, M = 130 -> Mp = 160 (two column tiles, the second partial)
+    dict(W=40, H=16, V=6, K=5, n_points=(17, 16), kind="matern52", lengthscale=0.1),   # M = 272 -> Mp = 288 (3 column tiles)
+    dict(W=25, H=20, V=8, K=4, n_points=(12,), one_d=True, lengthscale=0.2),          # 1-D
+]
+
+
+@pytest.mark.parametrize("case", ODD_SHAPES, ids=lambda c: "x".join(str(v) for v in (c["W"] * c["H"], c["K"]) + tuple(c["n_points"])))
+def test_default_fp32_build_on_odd_shapes(case):
+    """Loss and gradients of the default build (fp32 arrays, f64 solve, exact-split bf16 contractions) against the fp64 oracle
+    at identical parameters, on shapes that leave partial tiles, padded tile pairs and the fallback kernels."""
+    # a lengthscale of about one inducing spacing keeps K_uu + jitter well inside fp64: at 0.3 on a 13 x 10 grid the fp64
+    # oracle itself returns q = k^T K_uu^-1 k = 25 > variance, and every gradient downstream is conditioning noise
+    kw = dict(jitter=1e-4, lengthscale=0.08)
+    kw.update(case)
+    m, eps = make_oracle(dtype=torch.float64, **kw)
+    loss, grads = m.loss_and_grads(eps)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    errs = {}
+    for mode in ("f32", "bf16x6"):
+        eng = engine_from_oracle(m, dtype=torch.float32, mfma_mode=mode, store_t=False)
+        # same cumulative jitter on both sides: left alone, the engine decides the level in fp32 as the reference would (DESIGN.md section 3)
+        eng.loss_and_grads(dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=m.last_jitter_level)
+        out = eng.read_out()
+        assert abs(out["loss"] - loss) < 2e-5 * abs(loss), mode
+        errs[mode] = {}
+        for name in eng.PARAM_NAMES:
+            got, ref = eng.view(name, eng.grads).cpu().double().numpy(), grads[name].numpy()
+            assert np.isfinite(got).all(), (mode, name)
+            errs[mode][name] = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3 * gmax)
+    # fp32 conditioning (var = s^2 - |w|^2 + tt cancels) bounds both builds alike; the emulated contractions must not add to it
+    for name, e in errs["bf16x6"].items():
+        assert e < max(3 * errs["f32"][name], 5e-3), (name, errs)
+        assert e < 5e-2, (name, errs)
