@@ -22,6 +22,7 @@ SIGNATURES = {
     "gdrf_set_mfma_mode": (_int, [_vp, _int]),
     "gdrf_get_mfma_mode": (_int, [_vp]),
     "gdrf_set_whiten": (_int, [_vp, _int]),
+    "gdrf_set_mean": (_int, [_vp, _vp, _i64, _i64]),
     "gdrf_set_learn_inducing": (_int, [_vp, _int]),
     "gdrf_inducing_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_ctx_destroy": (None, [_vp]),

@@ -66,6 +66,8 @@ struct gdrf_ctx {
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
   hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join, ev_fact0, ev_fact;
   int fact_pending;           // a factorisation has been queued on the side stream: consumers wait for ev_fact
+  const void* mean;           // borrowed (K, n) mean_function values for the next gdrf_step_local calls, or null (zero_mean)
+  int64_t mean_sk, mean_sn;
   int unwhitened;             // whiten = False: u' = L^-1 u, S' = L^-1 S (solve-precision scratch below, allocated on demand)
   void *uS, *uSb, *uSc, *uU, *uUb, *Uw;
   int learn_z; double* zpart; // learnable inducing inputs: per-row-tile partial sums [ceil(ncap/128)][M][D]
@@ -158,7 +160,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->bf16x6 = 0;
-  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0;
+  c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0; c->mean = nullptr; c->mean_sk = c->mean_sn = 0;
   c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
@@ -279,6 +281,12 @@ int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
   c->bf16x6 = mode;
   return 0;
 }
+int gdrf_set_mean(gdrf_ctx* c, const void* mean, int64_t stride_k, int64_t stride_n) {
+  if (stride_k < 0 || stride_n < 0) return fail(-1, "gdrf_set_mean", "strides must be >= 0 (0 broadcasts)");
+  c->mean = mean; c->mean_sk = stride_k; c->mean_sn = stride_n;
+  return 0;
+}
+
 int gdrf_set_whiten(gdrf_ctx* c, int whiten) {
   if (whiten != 0 && whiten != 1) return fail(-1, "gdrf_set_whiten", "whiten must be 0 or 1");
   if (!whiten && c->Tst) return fail(-1, "gdrf_set_whiten", "whiten = 0 needs the dense Wbar form (GDRF_STORE_T_OFF)");
@@ -606,7 +614,7 @@ template <typename T, typename TS> struct Impl {
       int64_t nblk = (n + RB - 1) / RB;
       egrid = (int)std::min<int64_t>(nblk, c->erows_grid_cap);
       hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
-                         ldk, n, ws, P(c->phi), P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+                         ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
       LAUNCHCHK("elbo_rows");
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,

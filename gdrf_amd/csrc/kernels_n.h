@@ -691,6 +691,7 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     const T* __restrict__ qpart, int nqpart, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps,
     int64_t ldk, int64_t lde,
     const int32_t* __restrict__ ws, const T* __restrict__ phi,
+    const T* __restrict__ mean /*may be null*/, int64_t mean_sk, int64_t mean_sn,
     T* __restrict__ qout, T* __restrict__ vbar, T* __restrict__ locbar, T* __restrict__ asum, T* __restrict__ mu_out,
     double* __restrict__ dpart /*[grid][4]*/, T* __restrict__ phibar_part /*[grid][K*V]*/) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -725,6 +726,7 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
         ep[k] = eps[(int64_t)k * lde + n];
         v[k] = v0 + tt[(int64_t)k * ldk + n];
         mu[k] = loc[(int64_t)k * ldk + n] + v[k] * ep[k];
+        if (mean) mu[k] += mean[(int64_t)k * mean_sk + n * mean_sn];   // f_loc + mean_function(xs): the site terms only see mu - f_loc
         mx = fmax(mx, mu[k]);
       }
       T se = 0;

@@ -264,11 +264,13 @@ class Engine:
         raise RuntimeError("reached max jitter, covariance is unstable")
 
     def loss_and_grads(self, xs, ws, eps, n_global: Optional[int] = None, ll_const: Optional[float] = None,
-                       force_level: Optional[int] = None, renyi_alpha: Optional[float] = None):
+                       force_level: Optional[int] = None, renyi_alpha: Optional[float] = None, mean: Optional[torch.Tensor] = None):
         """One ELBO evaluation + backward.  Leaves d loss/d unconstrained in self.grads (device) and
-        returns nothing host-side; call read_out() for the loss."""
+        returns nothing host-side; call read_out() for the loss.  ``mean``: the values of the model's mean_function on these
+        rows, broadcastable to (K, n) (gdrf/models/sparse_gdrf.py:346,395); None = zero_mean."""
         self._chk_rows(xs, ws)
         n = xs.shape[0]
+        self._set_mean(mean, n)
         if eps.dim() == 2:
             eps = eps.unsqueeze(0)
         P = eps.shape[0]                          # particles (Trace_ELBO num_particles): the estimator is their mean
@@ -308,6 +310,19 @@ class Engine:
                 self.factorize(None)
                 self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
         self._guess_level = self.last_jitter_level if force_level is None else None
+
+    def _set_mean(self, mean, n: int):
+        if mean is None:
+            self._mean = None
+            _lib.check(self.lib.gdrf_set_mean(self.ctx, None, 0, 0), "gdrf_set_mean")
+            return
+        mean = torch.as_tensor(mean).detach().to(device=self.device, dtype=self.dtype)
+        try:
+            mean = mean.expand(self.K, n)                       # (n,), (K, 1), (K, n), scalars: torch broadcasting, as f_loc + mean
+        except RuntimeError:
+            raise ValueError(f"mean_function returned shape {tuple(mean.shape)}, not broadcastable to ({self.K}, {n})") from None
+        self._mean = mean                                       # keeps the storage alive while the context borrows it
+        _lib.check(self.lib.gdrf_set_mean(self.ctx, mean.data_ptr(), mean.stride(0), mean.stride(1)), "gdrf_set_mean")
 
     def _probe_level(self, stream_ptr: int) -> int:
         """First cumulative-jitter level whose array-precision Cholesky succeeds (probe only; raises past maxjitter)."""

@@ -89,7 +89,8 @@ class SVI:
         self.optim._bind(eng)
         n = xs_s.shape[0]
         eps = self._eps(eng, eps, n)
-        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale, renyi_alpha=getattr(self.loss, "alpha", None))
+        eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale, renyi_alpha=getattr(self.loss, "alpha", None),
+                           mean=model._mean_values(xs_s))
         self.optim._step()
         out = eng.read_out()
         self.steps_taken += 1
@@ -105,7 +106,7 @@ class SVI:
         eng = model._engine_for(xs_s.shape[0])
         n = xs_s.shape[0]
         eng.loss_and_grads(xs_s, ws_d, self._eps(eng, eps, n), n_global=1.0 / self.scale,
-                           renyi_alpha=getattr(self.loss, "alpha", None))
+                           renyi_alpha=getattr(self.loss, "alpha", None), mean=model._mean_values(xs_s))
         return float(eng.read_out()["loss"])
 
     def _eps(self, eng, eps, n):

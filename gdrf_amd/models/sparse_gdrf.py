@@ -96,11 +96,17 @@ class SparseMultinomialGDRF:
         seed: Optional[int] = None,
         **kwargs,
     ):
-        if mean_function is not None or link_function is not None:
-            raise NotImplementedError("custom mean_function / link_function: the HIP path fuses zero_mean and the softmax link "
-                                      "(gdrf/models/abstract_gdrf.py:17-22)")
-        if randomize_metric is not None:
-            raise NotImplementedError("randomize_metric")
+        if link_function is not None:
+            raise NotImplementedError("custom link_function: the HIP path fuses the softmax link and its Jacobian "
+                                      "(gdrf/models/abstract_gdrf.py:21-22)")
+        if mean_function is not None and not callable(mean_function):
+            raise TypeError("mean_function must be callable")
+        if randomize_metric is not None and not callable(randomize_metric):
+            raise TypeError("randomize_metric must be callable")
+        # abstract_gdrf.py:38-48: evaluated on the scaled inputs every step; its values are data to the fused step (no gradient
+        # flows into a mean_function's own parameters)
+        self._mean_function = mean_function
+        self._randomize_metric, self._randomize_iters = randomize_metric, int(randomize_iters)
         if not isinstance(kernel, Kernel):
             raise TypeError("kernel must be a gdrf_amd.kernels.RBF or Matern52")
         self._V = int(num_observation_categories)
@@ -161,6 +167,7 @@ class SparseMultinomialGDRF:
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
         if e is None:
+            self._engine = new                  # a randomize_metric may already call the model's methods
             self._init_params(new)
         else:                                   # grow the workspaces, keep parameters and optimizer state
             new.params.copy_(e.params); new.exp_avg.copy_(e.exp_avg); new.exp_avg_sq.copy_(e.exp_avg_sq)
@@ -180,7 +187,16 @@ class SparseMultinomialGDRF:
             eng.view("u_loc").zero_()
             ret = torch.softmax(self._dirichlet_param, dim=-2)           # over K (abstract_gdrf.py:68-69)
             if self._randomize_wt:
-                ret = torch.softmax(torch.randn(ret.shape, generator=self._gen, dtype=torch.float64), dim=-2)
+                # abstract_gdrf.py:70-78.  `best` is the score of the Dirichlet-parameter matrix and is never raised inside the
+                # loop, so the LAST candidate that beats it wins (with no metric: one draw, score 0 > best = -1).
+                metric = self._randomize_metric
+                as_model = lambda t: t.to(device=self.device, dtype=self.dtype)   # what the reference's metric is handed
+                best = -1 if metric is None else metric(as_model(ret), self)
+                for _ in range(1 if metric is None else self._randomize_iters):
+                    possible = torch.softmax(torch.randn(ret.shape, generator=self._gen, dtype=torch.float64), dim=-2)
+                    score = 0 if metric is None else metric(as_model(possible), self)
+                    if score > best:
+                        ret = possible
             eng.view("phi_unc").copy_(ret.log().to(eng.dtype))            # simplex transform inverse
             eng.factorize()                                               # u_scale_tril = jittercholesky(kernel(Z)) x K
             L = eng.workspace("L").to(eng.dtype)
@@ -230,6 +246,13 @@ class SparseMultinomialGDRF:
             if ws_d.shape != (xs_s.shape[0], self._V):
                 raise ValueError(f"ws must have shape ({xs_s.shape[0]}, {self._V})")
         return xs_s, ws_d
+
+    def _mean_values(self, xs_scaled: torch.Tensor) -> Optional[torch.Tensor]:
+        """mean_function(xs) on the scaled inputs (scale_decorator runs first: sparse_gdrf.py:323-346); None for zero_mean."""
+        if self._mean_function is None:
+            return None
+        with torch.no_grad():
+            return torch.as_tensor(self._mean_function(xs_scaled))
 
     # ------------------------------------------------------------------ SVI handles
     def model(self, xs, ws, subsample=False):

@@ -55,6 +55,13 @@ int gdrf_get_mfma_mode(const gdrf_ctx* ctx);
  * constructor's `whiten` argument): u_loc and u_scale_tril parameterise q(f(Z)) itself, the predictive uses
  * L^-1 u_loc and L^-1 u_scale_tril.  Default 1 (whitened), which is what the reference's train() always runs. */
 int gdrf_set_whiten(gdrf_ctx* ctx, int whiten);
+/* mean_function (gdrf/models/abstract_gdrf.py:17-18,33-48; applied as `f_loc + self._mean_function(xs)` in model and guide,
+ * gdrf/models/sparse_gdrf.py:346,395): `mean` is a BORROWED device array of the context's element type holding the values
+ * the callable returned for the rows of the next gdrf_step_local call(s), addressed as mean[k*stride_k + n*stride_n]
+ * (a stride of 0 broadcasts: the reference's (N,) return value is stride_k = 0, stride_n = 1).  NULL = zero_mean (default).
+ * The mean shifts the sampled mu that enters the link; the Normal site terms depend on mu - f_loc only, and - as in the
+ * reference - log_topic_probs / the predictive path do not add it (sparse_gdrf.py:161-186). */
+int gdrf_set_mean(gdrf_ctx* ctx, const void* mean, int64_t stride_k, int64_t stride_n);
 /* Learnable inducing inputs (gdrf/models/sparse_gdrf.py:79-88, fixed_inducing_points=False: a PyroParam under
  * stack([interval(0, 1)] * D), i.e. Z = sigmoid(unconstrained)).  The flat parameter vector always carries an (M, D)
  * block for the unconstrained values, gdrf_inducing_layout -> {offset, M*D}; the caller evaluates Z = sigmoid(block) and

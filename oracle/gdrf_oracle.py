@@ -170,8 +170,9 @@ class RefShapedGDRF:
                  dirichlet_param=0.01, jitter=1e-8, maxjitter=15, noise=1.0, dtype=torch.float64,
                  Z: Optional[torch.Tensor] = None, optimizer="adam", lr=1e-3,
                  force_jitter_level: Optional[int] = None, learn_inducing: bool = False, scale_mixture: float = 1.0,
-                 whiten: bool = True):
+                 whiten: bool = True, mean_function=None):
         self.dtype = dtype
+        self.mean_function = mean_function          # abstract_gdrf.py:33-48; None = zero_mean (abstract_gdrf.py:17-18)
         self.kind = kind
         self.K = K
         self.xs = torch.as_tensor(xs).to(dtype)
@@ -253,6 +254,8 @@ class RefShapedGDRF:
         Luu = self._luu(c)
         f_loc, f_var = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
                                    c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"], self.whiten)
+        if self.mean_function is not None:
+            f_loc = f_loc + self.mean_function(xs)        # sparse_gdrf.py:395
         q_mu = Normal(f_loc, f_var)                       # Q1: variance passed as scale
         mu = f_loc + f_var * eps                          # rsample with injected eps
         lq_mu = q_mu.log_prob(mu).sum()
@@ -260,6 +263,8 @@ class RefShapedGDRF:
         Luu2 = self._luu(c)
         f_loc2, f_var2 = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
                                      c["u_loc"], c["u_scale_tril"], Luu2, c["scale_mixture"], self.whiten)
+        if self.mean_function is not None:
+            f_loc2 = f_loc2 + self.mean_function(xs)      # sparse_gdrf.py:346
         lp_mu = Normal(f_loc2, f_var2 + c["noise"]).log_prob(mu).sum()
         lp_phi = Dirichlet(self.alpha).log_prob(c["phi"]).sum()
         topic_probs = torch.softmax(mu, -2).transpose(-2, -1)

@@ -10,7 +10,7 @@ NAME_MAP = dict(log_lengthscale="log_lengthscale", log_variance="log_variance", 
 
 def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.float64, seed=1, jitter=1e-6,
                 perturb=True, one_d=False, optimizer="adam", lr=1e-3, force_jitter_level=None, lengthscale=0.1,
-                learn_inducing=False, random_inducing=False, scale_mixture=1.0, whiten=True):
+                learn_inducing=False, random_inducing=False, scale_mixture=1.0, whiten=True, mean_function=None):
     xs, ws, _ = synth_circles(W, H, V, K, seed=seed, one_d=one_d)
     g = torch.Generator().manual_seed(seed + 100)
     Z = None
@@ -19,7 +19,7 @@ def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.f
         Z = 0.05 + 0.9 * torch.rand(M, 1 if one_d else 2, generator=g, dtype=torch.float64)
     m = RefShapedGDRF(xs, ws, kind=kind, K=K, n_points=n_points, dtype=dtype, jitter=jitter, optimizer=optimizer, lr=lr,
                       force_jitter_level=force_jitter_level, lengthscale=lengthscale, Z=Z, learn_inducing=learn_inducing,
-                      scale_mixture=scale_mixture, whiten=whiten)
+                      scale_mixture=scale_mixture, whiten=whiten, mean_function=mean_function)
     if perturb:
         with torch.no_grad():
             m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64).to(dtype))

@@ -504,3 +504,44 @@ def test_default_fp32_build_on_odd_shapes(case):
     for name, e in errs["bf16x6"].items():
         assert e < max(3 * errs["f32"][name], 5e-3), (name, errs)
         assert e < 5e-2, (name, errs)
+
+
+# ---- mean_function (abstract_gdrf.py:33-48; sparse_gdrf.py:346,395) -----------------------------------------------------
+def _mean_per_topic(xs):          # (K, N): a different trend for every topic
+    return torch.stack([(k + 1) * 0.7 * torch.sin(3.0 * xs[:, 0] + k) - 0.4 * k * xs[:, -1] for k in range(4)])
+
+
+MEANS = {
+    "per_topic_KxN": _mean_per_topic,
+    "per_topic_Kx1": lambda xs: torch.arange(4, dtype=xs.dtype, device=xs.device).unsqueeze(-1) * 6.0 - 9.0,
+    "reference_shape_N": lambda xs: 2.0 * xs[:, 0] - 1.0,      # xs.shape[:-1], like zero_mean: the softmax link cancels it
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("which", list(MEANS))
+def test_mean_function_values_enter_the_link(which, dtype):
+    fn = MEANS[which]
+    m, eps = make_oracle(dtype=torch.float64, K=4, W=21, H=13, n_points=(5, 4), mean_function=fn)
+    loss, grads = m.loss_and_grads(eps)
+    m0, _ = make_oracle(dtype=torch.float64, K=4, W=21, H=13, n_points=(5, 4))
+    loss0, _ = m0.loss_and_grads(eps)
+    if which == "reference_shape_N":
+        assert abs(loss - loss0) < 1e-12 * abs(loss0)          # a shift common to the K topics does not reach softmax(mu)
+    else:
+        assert abs(loss - loss0) > 2e-4 * abs(loss0)           # the case is not vacuous
+    eng = engine_from_oracle(m, dtype=dtype)
+    xs = dev(m.xs, eng)
+    eng.loss_and_grads(xs, dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=m.last_jitter_level, mean=fn(xs))
+    tol = 1e-9 if dtype == torch.float64 else 5e-3           # fp32: the hyper-parameter gradients carry the fp32 conditioning of the solve
+    ltol = LOSS_TOL_VS_TORCH if dtype == torch.float64 else 2e-5
+    assert abs(eng.read_out()["loss"] - loss) < ltol * abs(loss)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for name in eng.PARAM_NAMES:
+        got, ref = eng.view(name, eng.grads).cpu().double().numpy(), grads[name].numpy()
+        assert np.abs(got - ref).max() < tol * max(np.abs(ref).max(), 1e-3 * gmax), name
+    # the next call without a mean is the zero_mean step again (the borrowed pointer is dropped)
+    eng.loss_and_grads(xs, dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=m.last_jitter_level)
+    assert abs(eng.read_out()["loss"] - loss0) < ltol * abs(loss0)
+    with pytest.raises(ValueError):
+        eng.loss_and_grads(xs, dev(m.ws, eng, torch.int32), dev(eps, eng), mean=torch.zeros(3, 7))

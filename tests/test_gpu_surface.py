@@ -231,3 +231,61 @@ def test_learnable_inducing_points_like_the_reference_default():
     sd = model.state_dict()
     model.load_state_dict({k: v.clone() for k, v in sd.items()})
     assert torch.equal(model.inducing_points, z1)
+
+
+def test_mean_function_and_randomize_metric_through_the_model_surface():
+    """The constructor's callables (sparse_gdrf.py:26,34-37): mean_function is evaluated on the scaled inputs every step,
+    randomize_metric picks the initial word-topic matrix as abstract_gdrf.py:70-78 does (the last candidate beating the
+    score of the Dirichlet-parameter matrix)."""
+    from gdrf_amd import poutine
+    from gdrf_amd.infer import OBJECTIVE_DICT, SVI
+    from gdrf_amd.kernels import KERNEL_DICT
+    from gdrf_amd.models import GDRF_MODEL_DICT
+    from gdrf_amd.optim import OPTIMIZER_DICT
+    K, V = 3, 12
+    xs_np, ws_np, _ = synth_circles(20, 15, V, K, seed=5)
+    xs, ws = torch.from_numpy(xs_np).float().cuda(), torch.from_numpy(ws_np).int().cuda()
+    seen, scores, cands = [], [], []
+
+    def mean(x):
+        seen.append((tuple(x.shape), float(x.min()), float(x.max())))
+        return torch.stack([2.0 * x[:, 0], -2.0 * x[:, 0], x[:, 1]])
+
+    def metric(wt, model):
+        assert tuple(wt.shape) == (K, V) and abs(float(wt.sum(-2).mean()) - 1.0) < 1e-5 and model.K == K
+        scores.append(float(wt[0, 0]))                   # favour mass of taxon 0 on topic 0
+        cands.append(wt.detach().clone())
+        return scores[-1]
+
+    def build(**extra):
+        kern = KERNEL_DICT["rbf"](input_dim=2, lengthscale=torch.tensor(0.2), variance=torch.tensor(25.0))
+        return GDRF_MODEL_DICT["sparsemultinomialgdrf"](
+            xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=kern, num_observation_categories=V, device="cuda:0",
+            num_topic_categories=K, dirichlet_param=0.01, n_points=[5, 4], fixed_inducing_points=True, inducing_init="grid",
+            maxjitter=15, jitter=1e-6, seed=11, **extra)
+
+    model = build(mean_function=mean, randomize_wt_matrix=True, randomize_metric=metric, randomize_iters=7)
+    assert len(scores) == 8                                            # the Dirichlet-parameter matrix, then 7 candidates
+    beating = [c for sc, c in zip(scores[1:], cands[1:]) if sc > scores[0]]
+    assert beating, "seed gives no candidate above the uniform matrix"
+    # stored through the stacked-simplex transform (abstract_gdrf.py:79-84): the candidate's rows renormalised over V
+    chosen = beating[-1] / beating[-1].sum(-1, keepdim=True)
+    assert torch.allclose(model.word_topic_matrix, chosen, atol=1e-6)
+    plain = build()
+    start = model.state_dict()
+    scale = poutine.scale(scale=1.0 / len(xs))
+    losses = {}
+    for name, mdl in (("mean", model), ("plain", plain)):
+        mdl.load_state_dict(start)                                     # same parameters (randomised word-topic matrix): only the mean differs
+        svi = SVI(model=scale(mdl.model), guide=scale(mdl.guide), optim=OPTIMIZER_DICT["adam"]({"lr": 0.01}),
+                  loss=OBJECTIVE_DICT["elbo"](max_plate_nesting=1, vectorize_particles=True, num_particles=1))
+        eps = torch.randn(K, len(xs), generator=torch.Generator().manual_seed(3))
+        losses[name] = svi.evaluate_loss(xs=xs, ws=ws, eps=eps)
+        first = svi.step(xs=xs, ws=ws, eps=eps)
+        assert abs(first - losses[name]) < 1e-6 * abs(first)
+    assert seen and seen[0][0] == (len(xs), 2) and seen[0][1] >= 0.0 and seen[0][2] <= 1.0
+    assert abs(losses["mean"] - losses["plain"]) > 1e-4 * abs(losses["plain"])
+    # predictions ignore the mean, as the reference's log_topic_probs does (sparse_gdrf.py:161-186)
+    n_calls = len(seen)
+    model.topic_probs(xs)
+    assert len(seen) == n_calls

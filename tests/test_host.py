@@ -94,7 +94,11 @@ def test_model_rejects_options_outside_the_hot_path_before_touching_the_gpu():
     base = dict(num_observation_categories=5, num_topic_categories=2, world=[(0.0, 1.0)] * 2, kernel=k, dirichlet_param=0.01,
                 n_points=[3, 3], fixed_inducing_points=True)
     with pytest.raises(NotImplementedError):
-        SparseMultinomialGDRF(**{**base, "mean_function": lambda x: x})
+        SparseMultinomialGDRF(**{**base, "link_function": lambda x: x})
+    with pytest.raises(TypeError):
+        SparseMultinomialGDRF(**{**base, "mean_function": 1.0})
+    with pytest.raises(TypeError):
+        SparseMultinomialGDRF(**{**base, "randomize_metric": "best"})
     with pytest.raises(ValueError):
         SparseMultinomialGDRF(**{**base, "inducing_init": "hexagonal"})
     with pytest.raises(AssertionError):
