@@ -683,7 +683,10 @@ template <typename T, typename TS> struct Impl {
       } else {
         BwdKnmProb<TS, T> p{{}, {}, P(c->Wbar), n, M, Mp, c->D, c->kind, (const TS*)Q(c->LinvT), (const TS*)Q(c->Knm), X, (const TS*)Q(c->Zs), c->hyp,
                             c->dpart, nullptr};
-        hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
+        // capped at 160 registers where the LDS-transposed f64 epilogue runs: two of its waves then share a SIMD with one wave of
+        // G^T's TN contraction on the side stream (192 registers), which fills this kernel's stalls instead of queueing behind it
+        if (sizeof(TS) == 8) hipLaunchKernelGGL((gemm_nt_kernel_v160<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
       }
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 3, redd + 4);      // red_d[4..6]
     }

@@ -50,8 +50,22 @@ template <typename T> struct NTCfg {
 template <typename T> __device__ __forceinline__ int nt_stage_row(int i) { return (threadIdx.x >> 3) + 32 * i; }
 template <typename T> __device__ __forceinline__ int nt_stage_k() { return (threadIdx.x & 7) * NTCfg<T>::VE; }
 
+// workgroups per CU the register allocation must leave room for (a problem may declare `static constexpr int MIN_WGS`)
+template <class P, class = void> struct NTMinWgs { static constexpr int value = 2; };
+template <class P> struct NTMinWgs<P, decltype((void)P::MIN_WGS)> { static constexpr int value = P::MIN_WGS; };
+
+template <typename T, class P> __device__ __forceinline__ void gemm_nt_body(P& p);
+
 template <typename T, class P>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(P p) {
+__global__ __launch_bounds__(256, NTMinWgs<P>::value) void gemm_nt_kernel(P p) { gemm_nt_body<T, P>(p); }
+
+// the same kernel capped at 160 registers: two of its waves and one 192-register wave (the bf16 TN contraction) fit a SIMD's
+// 512 registers together.  (amdgpu_num_vgpr takes a literal only, hence a second entry point.)
+template <typename T, class P>
+__global__ __launch_bounds__(256, 3) __attribute__((amdgpu_num_vgpr(80))) void gemm_nt_kernel_v160(P p) { gemm_nt_body<T, P>(p); }
+
+template <typename T, class P>
+__device__ __forceinline__ void gemm_nt_body(P& p) {
   using C = NTCfg<T>;
   using V = typename Vec16<T>::type;
   using MM = Mfma<T>;

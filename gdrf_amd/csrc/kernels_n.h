@@ -549,6 +549,7 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
 // learnable inducing inputs needs (sparse_gdrf.py:79-88, fixed_inducing_points=False); one partial per (row tile, column).
 template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
   using V = typename Vec16<T>::type;
+  static constexpr int MIN_WGS = (sizeof(T) == 8 && !LZ) ? 3 : 2;   // f64: three workgroups per CU hide each other's epilogues
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
   static constexpr int DEPTH = 1;
@@ -598,10 +599,109 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
     const int c = n0 + nt_stage_row<T>(i);
     return (c < Mp) ? *reinterpret_cast<const V*>(LinvT + (int64_t)c * Mp + k) : vzero<T>();
   }
+  // per-strip arithmetic of the f64 epilogue for one kernel kind (straight-line: no per-element branch on the kind)
+  typedef T KT2 __attribute__((ext_vector_type(2)));
+  template <int KD, int DD, int NR>
+  __device__ __forceinline__ void strip_math(const KT2 (&kv)[NR], const T* __restrict__ trow, int tstride, const TN (&x)[NR][DD],
+                                             const T (&zc)[2][DD], const bool (&rok)[NR], const bool (&cok)[2],
+                                             T ils2, T al, ECtx& e) const {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const KT2 kb = *reinterpret_cast<const KT2*>(trow + 4 * i * tstride);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const T kbar = (rok[i] && cok[j]) ? kb[j] : T(0);
+        const T kvv = kv[i][j];
+        T r2 = 0;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) { const T t = (d < D ? (T)x[i][d] : T(0)) - zc[j][d]; r2 += t * t; }
+        r2 *= ils2;
+        e.s1 += kbar * kvv;
+        e.s2 += kbar * dcov_dlogls_from_k<T>(KD, kvv, r2, al);
+        if constexpr (KD == 4) e.s3 += kbar * dcov_dlogalpha_from_k<T>(KD, kvv, r2, al);
+        if constexpr (LZ) {
+          const T w = kbar * dcov_dr2_from_k<T>(KD, kvv, r2, al);
+#pragma unroll
+          for (int d = 0; d < DD; ++d) e.zs[j][d] += w * (zc[j][d] - (d < D ? (T)x[i][d] : T(0)));
+        }
+      }
+    }
+  }
+  // f64 solve.  The accumulator layout (lane = column, 4 scattered rows) makes the K_nm reads of the straightforward
+  // epilogue 32 dependent 8-byte loads per lane, which took as long as the GEMM loop.  Each wave instead transposes its
+  // 64 x 32 quadrant through a private LDS tile, 16 rows at a time, so that a lane owns two adjacent columns: K_nm comes in
+  // as four independent 16-byte loads per strip (a row segment of 256 B per 16 lanes).  Addresses are 32-bit offsets from
+  // the tile's uniform base pointers (64-bit per-row addresses for the whole tile, hoisted above the strips, spilled).
+  template <int DD, class Acc, int NB_>
+  __device__ __forceinline__ void epi_f64(Acc (&acc)[4][NB_], int64_t m0, int n0, ECtx& e, int wr, int wc, int lane) const {
+    if (m0 >= nrows) return;                                // a padding workgroup of the XCD-aware grid (uniform: no barrier is skipped by a part of it)
+    const T ils2 = (T)h->inv_ls2, al = (T)h->alpha;
+    extern __shared__ __attribute__((aligned(16))) char nt_smem[];
+    constexpr int TS_ = 48;                                 // tile row stride in doubles: consecutive rows 128 B apart mod 256
+    T* tile = reinterpret_cast<T*>(nt_smem) + (threadIdx.x >> 6) * (16 * TS_);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nc = n0 + wc * (NTCfg<T>::CW / 2) + 2 * lr;  // this lane's columns nc, nc + 1
+    const int ncl = nc < Mp ? nc : 0;                       // Mp is even: a pair never straddles the padded edge
+    const bool cok[2] = {nc < M, nc + 1 < M};
+    T zc[2][DD];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nz = cok[j] ? nc + j : 0;
+#pragma unroll
+      for (int d = 0; d < DD; ++d) { const T v = Z[nz * D + (d < D ? d : 0)]; zc[j][d] = d < D ? v : T(0); }
+    }
+    const T* __restrict__ Kt = Knm + m0 * Mp;              // uniform bases of this row tile
+    const TN* __restrict__ Xt = X + m0 * D;
+    const int rmax = (int)((nrows - m0 < GDRF_TILE ? nrows - m0 : GDRF_TILE) - 1);   // last valid row of the tile (m0 < nrows)
+    const int r0 = wr * 64 + lg;                            // strip a, slot i: tile row r0 + a * 16 + 4 * i
+    __syncthreads();                                        // every wave is done with the operand images of the last chunk
+    constexpr int NR = 2;                                   // rows per load batch: 4 cost 8 more registers (166: no longer two waves beside a TN wave)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int hb = 0; hb < 4 / NR; ++hb) {
+        KT2 kv[NR]; TN x[NR][DD]; bool rok[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int rl = r0 + a * 16 + 4 * (hb * NR + i);
+          rok[i] = rl <= rmax;
+          const unsigned rc = (unsigned)(rok[i] ? rl : rmax);
+          kv[i] = *reinterpret_cast<const KT2*>(Kt + (rc * (unsigned)Mp + (unsigned)ncl));
+#pragma unroll
+          for (int d = 0; d < DD; ++d) x[i][d] = Xt[rc * (unsigned)D + (unsigned)(d < D ? d : 0)];
+        }
+        if (hb == 0) {
+#pragma unroll
+          for (int b = 0; b < NTCfg<T>::NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(lg + 4 * r) * TS_ + b * 16 + lr] = acc[a][b][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave writes and reads: LDS is in order per wave
+        }
+        const T* trow = tile + (lg + 4 * hb * NR) * TS_ + 2 * lr;   // slot i: row lg + 4 * (hb * NR + i) of the strip
+        switch (kind) {
+          case 0: strip_math<0, DD, NR>(kv, trow, TS_, x, zc, rok, cok, ils2, al, e); break;
+          case 1: strip_math<1, DD, NR>(kv, trow, TS_, x, zc, rok, cok, ils2, al, e); break;
+          case 2: strip_math<2, DD, NR>(kv, trow, TS_, x, zc, rok, cok, ils2, al, e); break;
+          case 3: strip_math<3, DD, NR>(kv, trow, TS_, x, zc, rok, cok, ils2, al, e); break;
+          default: strip_math<4, DD, NR>(kv, trow, TS_, x, zc, rok, cok, ils2, al, e); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                  // one batch at a time
+      }
+    }
+  }
   template <class Acc, int NB_>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int, ECtx& e, int wr, int wc, int lane) const {
     const T ils2 = (T)h->inv_ls2, al = (T)h->alpha;
     e.n0 = n0;
+#ifndef GDRF_BWDKNM_SCALAR_EPILOGUE
+    if constexpr (sizeof(T) == 8 && !LZ) {
+      if (D <= 2) {            // the reference's worlds are 1-D (time) or 2-D (space); more dimensions take the generic form below
+        epi_f64<2>(acc, m0, n0, e, wr, wc, lane);
+        return;
+      }
+    }
+#endif
     T z[4][GDRF_DMAX];
 #pragma unroll
     for (int b = 0; b < NTCfg<T>::NB; ++b) {
@@ -638,6 +738,11 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
         }
       }
   }
+  // column (inside the workgroup tile) of the lane's bb-th inducing-point gradient sum: the accumulator column, or the
+  // adjacent pair the LDS-transposed f64 epilogue gives the lane
+  static __device__ __forceinline__ int zcol(int wc, int bb, int lane) {
+    return nt_acc_col<T>(wc, bb, lane);
+  }
   __device__ __forceinline__ void finish(int64_t m0, int, ECtx& e, char* smem, int wr, int wc, int lane) const {
     double* scratch = reinterpret_cast<double*>(smem);
     __syncthreads();
@@ -662,14 +767,14 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
 #pragma unroll
         for (int bb = 0; bb < NTCfg<T>::NB; ++bb)
 #pragma unroll
-          for (int d = 0; d < GDRF_DMAX; ++d) zb[nt_acc_col<T>(wc, bb, lane) * GDRF_DMAX + d] = (double)e.zs[bb][d];
+          for (int d = 0; d < GDRF_DMAX; ++d) zb[zcol(wc, bb, lane) * GDRF_DMAX + d] = (double)e.zs[bb][d];
       }
       __syncthreads();
       if (wr == 0 && (lane >> 4) == 0 && m0 < nrows) {
         const int64_t rt = m0 / GDRF_TILE;
 #pragma unroll
         for (int bb = 0; bb < NTCfg<T>::NB; ++bb) {
-          const int cl = nt_acc_col<T>(wc, bb, lane), n = e.n0 + cl;
+          const int cl = zcol(wc, bb, lane), n = e.n0 + cl;
           if (n < M)
             for (int d = 0; d < D; ++d) zpart[(rt * M + n) * D + d] = (double)e.zs[bb][d] + zb[cl * GDRF_DMAX + d];
         }
