@@ -583,7 +583,9 @@ struct TNBf16Args {
 __device__ __forceinline__ int tnb_code(int k) { return (((k >> 3) & 1) << 2) | (k & 3); }
 __device__ __forceinline__ int tnb_seg(int k, int c4) { return k * 32 + (c4 ^ (tnb_code(k) << 2)); }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
+// 192 registers at most (amdgpu_num_vgpr counts half of the unified file): one wave of this kernel then shares a SIMD's 512 with two
+// 160-register waves of bwd_knm on the other stream (api.hip), which is how G^T runs inside that kernel's stalls
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
   constexpr int PIECE = 32 * 128;             // halfwords per piece image (8 KB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* As = reinterpret_cast<__bf16*>(smem);           // [2 buffers][3][32][128]
@@ -674,6 +676,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
+  // symmetric problem, diagonal tile: the quadrant above the diagonal (rows 0-63 x columns 64-127) is the mirror image of the one
+  // below it and reduce_slabs_kernel takes it from there.  Its wave skips fragment reads and MFMAs - a quarter of the tile's LDS
+  // read traffic, which is what bounds this kernel - and only stages.
+  const bool idle = g.sym && ti == tj && __builtin_amdgcn_readfirstlane(wave) == 1;
   if (nch > 0) { dma_a(0); load_b(0); }
   for (int c = 0; c < nch; ++c) {
     // scale and split the prefetched B vectors BEFORE the barrier: the conversion then overlaps the other waves' MFMAs
@@ -697,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
     }
     __syncthreads();
     if (c + 1 < nch) { dma_a(c + 1); load_b(c + 1); }          // A buffer (c+1)&1 was last read in iteration c-1
+    if (idle) continue;                                        // staged and synchronised with the others; nothing of its own to multiply
     const __bf16* Ab = As + (c & 1) * 3 * PIECE;
     bf16x8 fb[3][4];
 #pragma unroll
@@ -722,6 +729,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
       for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][t], acc[a][t], 0, 0, 0);
     }
   }
+  if (idle) return;
   float* out = g.slab + ((int64_t)sp * g.nbatch + b) * (int64_t)g.ncols * g.ncols;
 #pragma unroll
   for (int a = 0; a < 4; ++a)

@@ -976,12 +976,15 @@ template <typename T>
 __global__ void reduce_slabs_kernel(const T* __restrict__ slab, int nsplit, int nbatch, int Mp, int sym, T* __restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
   if (j >= Mp) return;
-  if (sym && (j / GDRF_TILE) > (i / GDRF_TILE)) return;
+  // sym: 64 x 64 quadrants above the diagonal are mirrored from below (a diagonal tile's upper-right quadrant is not computed
+  // by the bf16 TN kernel; the f32 one computes it, to the same values up to the summation order)
+  constexpr int QD = GDRF_TILE / 2;
+  if (sym && (j / QD) > (i / QD)) return;
   const int64_t mm = (int64_t)Mp * Mp;
   double s = 0;
   for (int sp = 0; sp < nsplit; ++sp) s += (double)slab[((int64_t)sp * nbatch + b) * mm + (int64_t)i * Mp + j];
   out[(int64_t)b * mm + (int64_t)i * Mp + j] = (T)s;
-  if (sym && (j / GDRF_TILE) < (i / GDRF_TILE)) out[(int64_t)b * mm + (int64_t)j * Mp + i] = (T)s;
+  if (sym && (j / QD) < (i / QD)) out[(int64_t)b * mm + (int64_t)j * Mp + i] = (T)s;
 }
 
 // =====================================================================================
