@@ -910,41 +910,71 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
 }
 
 // =====================================================================================
-// ubar partials: ubar[k][i] = sum_n locbar[k][n] W[n][i]; thread owns a column, 16 topics at a time
+// ubar partials: ubar[k][i] = sum_n locbar[k][n] W[n][i].  A workgroup covers 256 columns x rows_per_blk rows: lane = 4 adjacent
+// columns (one 16-byte W load per row, 1 KB per wave), wave = every fourth row, 16 topics at a time; locbar goes through LDS as
+// [row][16 topics] so that a row's 16 factors are four broadcast 16-byte reads (the one-column form issued 16 LDS reads and one 4-byte
+// load per 16 FMAs and ran at 1 TB/s).  The four waves' sums meet in LDS in a fixed order.
 // =====================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void ubar_part_kernel(const T* __restrict__ W, int64_t nrows, int Mp, int K,
                                                         const T* __restrict__ locbar, int64_t ldk, int64_t rows_per_blk,
                                                         T* __restrict__ part /*[gridDim.x][K][Mp]*/) {
-  __shared__ T lb[16][256];
-  const int col = blockIdx.y * 256 + threadIdx.x;
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) T lb[256][16];
+  const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.y * 256 + 4 * cq;               // Mp is a multiple of 32: a quad is inside or outside as a whole
+  const bool cok = col < Mp;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk; if (r1 > nrows) r1 = nrows;
   for (int k0 = 0; k0 < K; k0 += 16) {
-    T acc[16];
+    T4 acc[16];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc[kk] = 0;
+    for (int kk = 0; kk < 16; ++kk) acc[kk] = T4{0, 0, 0, 0};
     for (int64_t rs = r0; rs < r1; rs += 256) {
       __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
+      {
         const int64_t n = rs + threadIdx.x;
-        lb[kk][threadIdx.x] = (k0 + kk < K && n < r1) ? locbar[(int64_t)(k0 + kk) * ldk + n] : T(0);
+        T v[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) v[kk] = (k0 + kk < K && n < r1) ? locbar[(int64_t)(k0 + kk) * ldk + n] : T(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<T4*>(&lb[threadIdx.x][4 * q]) = T4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
       }
       __syncthreads();
       const int cnt = (int)((r1 - rs < 256) ? (r1 - rs) : 256);
-      if (col < Mp) {
-        for (int r = 0; r < cnt; ++r) {
-          const T w = W[(rs + r) * Mp + col];
+      if (cok) {
+        const T* wp = W + rs * Mp + col;
+#pragma unroll 4
+        for (int r = rg; r < cnt; r += 4) {
+          const T4 w = *reinterpret_cast<const T4*>(wp + (int64_t)r * Mp);
 #pragma unroll
-          for (int kk = 0; kk < 16; ++kk) acc[kk] += lb[kk][r] * w;
+          for (int q = 0; q < 4; ++q) {
+            const T4 l = *reinterpret_cast<const T4*>(&lb[r][4 * q]);
+            acc[4 * q] += l[0] * w; acc[4 * q + 1] += l[1] * w; acc[4 * q + 2] += l[2] * w; acc[4 * q + 3] += l[3] * w;
+          }
         }
       }
     }
-    if (col < Mp) {
+    // waves 1..3 hand their sums to wave 0 through LDS (lb is free: 4 topics x 3 waves x 64 lanes x 16 B = 12 KB per pass)
+    T4* red = reinterpret_cast<T4*>(&lb[0][0]);
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
-        if (k0 + kk < K) part[((int64_t)blockIdx.x * K + k0 + kk) * Mp + col] = acc[kk];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      __syncthreads();
+      if (rg > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[((rg - 1) * 4 + j) * 64 + cq] = acc[4 * g4 + j];
+      }
+      __syncthreads();
+      if (rg == 0 && cok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = 4 * g4 + j;
+          T4 t = acc[kk];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) t += red[(w * 4 + j) * 64 + cq];
+          if (k0 + kk < K) *reinterpret_cast<T4*>(part + ((int64_t)blockIdx.x * K + k0 + kk) * Mp + col) = t;
+        }
+      }
     }
   }
 }
