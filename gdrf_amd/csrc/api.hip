@@ -444,7 +444,7 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), f, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
       hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
       hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, f, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
-      hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(1024), 0, f, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
+      hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(256), 0, f, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
                          Q(c->LinvT));
     }
     HIPCHK(hipEventRecord(c->ev_fact, f));

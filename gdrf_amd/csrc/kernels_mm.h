@@ -297,43 +297,66 @@ __global__ __launch_bounds__(64) void trinv_diag_kernel(const T* __restrict__ L,
   }
 }
 
-// block column J of Linv = L^{-1}; one 1024-thread workgroup per block column.
-//   X[J][J] = Dinv[J];   X[I][J] = -Dinv[I] * sum_{P=J}^{I-1} L[I][P] X[P][J]
+// block ROW I of X = L^{-1}; one 256-thread workgroup per block row, one wave per 16x16 quadrant of a 32x32 block.  From X L = 1:
+//   X[I][I] = Dinv[I];   X[I][J] = -(sum_{P=J+1}^{I} X[I][P] L[P][J]) Dinv[J],  J = I-1 .. 0
+// The 32x32x32 tile products run on the matrix cores with both operands fetched straight from L2 in MFMA fragment order: the right
+// operand L[P][J] with its columns across the lanes, the left operand X[I][P] out of the TRANSPOSED copy this kernel writes anyway
+// (XT[P][I]: its rows across the lanes) - 128-byte segments on both sides, no LDS staging, PB tile pairs per round trip.  Only the
+// product with Dinv[J] needs the sum turned from the accumulator layout into a left operand, through one 32x32 LDS tile.
+// (History: the scalar column form - every thread 32 LDS-fed FMAs per tile product - was LDS-bound, 310-335 us at M = 512 f64;
+// the MFMA column form with L as the left operand, 32-byte strided segments, 190 us.)
 template <typename T>
-__global__ __launch_bounds__(1024) void trinv_cols_kernel(const T* __restrict__ L, const T* __restrict__ Dinv, int M, int Mp,
-                                                         T* __restrict__ X, T* __restrict__ XT) {
-  __shared__ T Sa[32][33];
-  __shared__ T Sb[32][33];
-  const int J = blockIdx.x, nb = Mp / 32;
-  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  auto put = [&](int I, T v) {
-    const int gi = I * 32 + ty, gj = J * 32 + tx;
+__global__ __launch_bounds__(256) void trinv_cols_kernel(const T* __restrict__ L, const T* __restrict__ Dinv, int M, int Mp,
+                                                        T* __restrict__ X, T* __restrict__ XT) {
+  using MM = Mfma<T>;
+  using acc_t = typename MM::acc_t;
+  __shared__ T Sx[32][33];
+  const int I = blockIdx.x, nb = Mp / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  auto put = [&](int J, int r, int c, T v) {
+    const int gi = I * 32 + r, gj = J * 32 + c;
     if (gi >= M || gj >= M) v = 0;
     X[(int64_t)gi * Mp + gj] = v;
     XT[(int64_t)gj * Mp + gi] = v;
   };
-  // blocks above the diagonal are zero
-  for (int I = 0; I < J; ++I) put(I, T(0));
-  put(J, Dinv[(int64_t)J * 1024 + ty * 32 + tx]);
+  // blocks right of the diagonal are zero
+  for (int J = I + 1; J < nb; ++J)
+    for (int e = tid; e < 1024; e += 256) put(J, e >> 5, e & 31, T(0));
+  for (int e = tid; e < 1024; e += 256) put(I, e >> 5, e & 31, Dinv[(int64_t)I * 1024 + e]);
+  __threadfence_block();
   __syncthreads();
-  for (int I = J + 1; I < nb; ++I) {
-    T acc = 0;
-    for (int P = J; P < I; ++P) {
-      Sa[ty][tx] = L[(int64_t)(I * 32 + ty) * Mp + P * 32 + tx];
-      Sb[ty][tx] = X[(int64_t)(P * 32 + ty) * Mp + J * 32 + tx];
-      __syncthreads();
+  constexpr int PB = 4;
+  const T* xt = XT + (int64_t)lg * Mp + I * 32 + wr * 16 + lr;         // + (P*32 + 4*kk)*Mp          : left fragment element [row lr][k lg] = X[I][P][row][k]
+  const T* lp = L + (int64_t)lg * Mp + wc * 16 + lr;                   // + (P*32 + 4*kk)*Mp + J*32   : right fragment element [k lg][col lr]
+  for (int J = I - 1; J >= 0; --J) {
+    acc_t acc = acc_t{0, 0, 0, 0};
+    for (int P0 = J + 1; P0 <= I; P0 += PB) {
+      T a[PB][8], b[PB][8];
 #pragma unroll
-      for (int p = 0; p < 32; ++p) acc += Sa[ty][p] * Sb[p][tx];
-      __syncthreads();
+      for (int u = 0; u < PB; ++u) {
+        const int P = (P0 + u <= I) ? P0 + u : P0;                      // clamped: surplus loads repeat a valid tile and are not used
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          a[u][kk] = xt[(int64_t)(P * 32 + 4 * kk) * Mp];
+          b[u][kk] = lp[(int64_t)(P * 32 + 4 * kk) * Mp + J * 32];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PB; ++u)
+        if (P0 + u <= I) {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) acc = MM::mma(a[u][kk], b[u][kk], acc);
+        }
     }
-    Sa[ty][tx] = acc;
-    Sb[ty][tx] = Dinv[(int64_t)I * 1024 + ty * 32 + tx];
-    __syncthreads();
-    T o = 0;
 #pragma unroll
-    for (int p = 0; p < 32; ++p) o += Sb[ty][p] * Sa[p][tx];
+    for (int r = 0; r < 4; ++r) Sx[wr * 16 + MM::crow(lane, r)][wc * 16 + lr] = acc[r];
     __syncthreads();
-    put(I, -o);
+    acc_t o = acc_t{0, 0, 0, 0};
+    const T* dj = Dinv + (int64_t)J * 1024 + lg * 32 + wc * 16 + lr;    // [k lg][col lr]
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) o = MM::mma(Sx[wr * 16 + lr][4 * kk + lg], dj[4 * kk * 32], o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) put(J, wr * 16 + MM::crow(lane, r), wc * 16 + lr, -o[r]);
     __threadfence_block();
     __syncthreads();
   }
