@@ -181,10 +181,12 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
         x[j] = (l == j) ? piv : ((l > j) ? x[j] * rp : T(0));
         if constexpr (sizeof(T) == 4) {
           // f32: the column reaches the other lanes through v_readlane (compile-time lane index, no LDS round trip)
+          // no (l >= c) predicate: entries above the diagonal are never read (step c zeroes them), and a select per element
+          // doubled the instruction count of this serial chain
 #pragma unroll
           for (int c = j + 1; c < 32; ++c) {
             const T lcj = chol_readlane(x[j], c);
-            if (l >= c) x[c] -= x[j] * lcj;
+            x[c] -= x[j] * lcj;
           }
         } else {
           // f64: two readlanes per value plus their hazards measured slower than a broadcast through LDS
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
 #pragma unroll
           for (int c = j + 1; c < 32; ++c) {
             const T lcj = Scol[c];
-            if (l >= c) x[c] -= x[j] * lcj;
+            if (l >= c) x[c] -= x[j] * lcj;               // (f64: dropping this predicate as in the f32 branch measured 1.5x SLOWER)
           }
           __builtin_amdgcn_wave_barrier();
         }
