@@ -152,8 +152,59 @@ __global__ __launch_bounds__(1024) void chol_kernel(T* __restrict__ A, int M, in
       __syncthreads();
     }
     CHOL_TICK(0)
-    // ---- (b) factor the 32x32 diagonal block: one wave, one row per lane, rows in registers
-    if (wave == 0) {
+    // ---- (b) factor the 32x32 diagonal block: one wave, rows in registers
+    if (wave == 0 && sizeof(T) == 8) {
+      // f64: a row per lane PAIR - lane l holds the even columns of row l, lane l + 32 the odd ones - so that the 31-column update
+      // of a pivot step, the bulk of this serial chain (47 % of the kernel), is half as many instructions.  The scaled pivot column
+      // reaches every lane through LDS (Scol): its own row's entry as the multiplier, the other rows' entries as broadcasts.
+      const int l = lane & 31, half = lane >> 5;
+      T xh[16];                                // xh[i] = U[l][2 i + half]
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = 2 * i + half;
+        const bool in = (c0 + l < M) && (c0 + c < M);
+        xh[i] = in ? A[(int64_t)(c0 + l) * ld + c0 + c] : ((l == c) ? T(1) : T(0));
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int jh = j & 1, ji = j >> 1;
+        T d = chol_readlane(xh[ji], j + 32 * jh);             // U[j][j]: row j, in the half that owns column j
+        if (!(d > T(0))) { if (lane == 0 && c0 + j < M) *flag = 1; d = T(1); }
+        double y = __builtin_amdgcn_rsq((double)d);
+        y = y * (1.5 - 0.5 * d * y * y);
+        y = y * (1.5 - 0.5 * d * y * y);
+        double p0 = d * y;
+        p0 = p0 + 0.5 * y * (d - p0 * p0);
+        const T piv = (T)p0, rp = (T)(y + y * (1.0 - p0 * y));
+        if (half == jh) {
+          const T colv = (l == j) ? piv : ((l > j) ? xh[ji] * rp : T(0));
+          xh[ji] = colv;
+          Scol[l] = colv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const T xj = Scol[l];                                  // L[l][j]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (2 * i + 1 > j) {                                 // compile time: some half still has a column right of j at index i
+            const int c = 2 * i + half;
+            const T lcj = Scol[c];                             // L[c][j]
+            if (l >= c && c > j) xh[i] -= xj * lcj;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      T dg = T(1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = 2 * i + half;
+        Sa[l][c] = xh[i];
+        if (c0 + l < M && c0 + c < M) A[(int64_t)(c0 + l) * ld + c0 + c] = xh[i];
+        if (c == l) dg = xh[i];
+      }
+      if (half == (l & 1)) Scol[l] = T(1) / dg;                // reciprocal pivots for the rows below (after the last step's readers)
+    } else if (wave == 0) {
       const int l = lane & 31;                 // lanes 32..63 mirror lanes 0..31 (same values, same writes)
       T x[32];
 #pragma unroll
