@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B on one box: bench with the in-tree library, then with tools/<alt>.so copied over it, then the in-tree one again
+# A/B on ONE GPU box (the pool's boxes differ by ~5 %): bench with the in-tree library, then with tools/<alt>.so copied over it, twice.
+# Build the alternative first, e.g. an older commit's api.hip or a -D switch:
+#   (cd gdrf_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DGDRF_BWDKNM_SCALAR_EPILOGUE -shared -o ../../tools/alt.so api.hip)
+#   gpurun -- 'bash tools/ab.sh alt.so'
 set -e
 ALT=$1; shift
 L=gdrf_amd/csrc/libgdrf_hip.so
