@@ -28,10 +28,13 @@ SIGNATURES = {
     "gdrf_ctx_destroy": (None, [_vp]),
     "gdrf_param_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_red_layout": (_int, [_vp, C.POINTER(_i64)]),
+    "gdrf_payload_pack": (_int, [_vp, _vp, _vp, _vp]),
+    "gdrf_payload_unpack": (_int, [_vp, _vp, _vp, _vp]),
     "gdrf_set_dirichlet": (_int, [_vp, C.POINTER(_dbl)]),
     "gdrf_knm": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gdrf_fill_eps": (_int, [_vp, C.c_uint64, C.c_uint32, _i64, _i64, _vp, _vp]),
     "gdrf_ll_const": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), _vp]),
+    "gdrf_ll_const_dev": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "gdrf_probe": (_int, [_vp, _vp, _vp, C.POINTER(_dbl), _int, C.POINTER(_int), _vp]),
     "gdrf_factorize": (_int, [_vp, _vp, _vp, _dbl, _vp]),
     "gdrf_step_local": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -3,7 +3,7 @@
 #include "common.h"
 #include "gemm_nt.h"
 #include "gemm_tn.h"
-#include "gemm_bf16x6.h"
+#include "gemm_split.h"
 #include "kernels_mm.h"
 #include "kernels_n.h"
 
@@ -54,12 +54,15 @@ struct gdrf_ctx {
   // N-side precision
   void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
-  void *Bh, *STh, *Wh;        // 3 bf16 pieces each of B_k, S_k^T and W (f32 contexts; exact-split bf16 MFMA forms)
-  int bf16x6;                 // 1: Wbar contraction on the bf16 matrix path with exact-split emulation (gemm_bf16x6.h)
+  void *Bh, *STh, *Wh;        // 16-bit pieces of B_k, S_k^T and W (f32 contexts; split-operand MFMA forms, gemm_split.h)
+  int split;                  // 0: native f32 MFMA; 1: "bf16x6" (3 bf16 pieces, 6 products); 2: "f16x3" (2 fp16 pieces, 3 products, block scales)
+  int wh_pieces;              // pieces Wh has room for
+  float* ssc; unsigned* smx;  // block scales (SplitLay pairs) and the maxima they come from
   void *Tst;                  // T_k = W S_k kept for the backward, or nullptr (dense W B_k form instead)
   int64_t t_bs, t_ts;         // its per-topic / per-row-tile strides in elements
   void *slab, *ubar_part, *phibar_part;
-  double *dpart, *dsmall;     // dsmall: [0..1] kuu sums, [8] ll_const scratch
+  double *dpart, *dsmall;     // dsmall: [0..2] kuu sums, [8] ll_const scratch
+  double *llpart;             // per-workgroup partials of the data constant (own buffer: it may be queued beside a step)
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
   double* alpha_dev; double lgam_const;
   Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[8..16): probe levels failed
@@ -109,8 +112,11 @@ static int64_t poff(const gdrf_ctx* c, int which) {
 static int64_t roff(const gdrf_ctx* c, int which) {
   const int64_t mm = (int64_t)c->Mp * c->Mp;
   const int64_t o_ubar = 0, o_phib = round_up((int64_t)c->K * c->Mp, 4), o_A = round_up(o_phib + (int64_t)c->K * c->V, 4);
-  const int64_t o_GT = o_A + c->K * mm, total = o_GT + mm;
-  switch (which) { case 0: return o_ubar; case 1: return o_phib; case 2: return o_A; case 3: return o_GT; default: return total; }
+  const int64_t o_GT = o_A + c->K * mm, o_tail = o_GT + mm;
+  // tail: the doubles of red_d for the step's single all-reduce (gdrf_payload_pack): as they are in f64 contexts, four float
+  // pieces each in f32 ones
+  const int64_t nd = 8 + (int64_t)c->M * c->D, total = o_tail + round_up(c->esz == 8 ? nd : 4 * nd, 4);
+  switch (which) { case 0: return o_ubar; case 1: return o_phib; case 2: return o_A; case 3: return o_GT; case 5: return o_tail; default: return total; }
 }
 
 int gdrf_param_layout(const gdrf_ctx* c, int64_t out[7]) { for (int i = 0; i < 7; ++i) out[i] = poff(c, i); return 0; }
@@ -166,7 +172,7 @@ int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int
 
 int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id, int store_t) {
   if (!out || n_cap < 1 || M < 1 || K < 1 || V < 1 || D < 1) return fail(-1, "gdrf_ctx_create", "bad size");
-  if (K > GDRF_KMAX) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 32 not supported");
+  if (K > GDRF_TILE) return fail(-1, "gdrf_ctx_create", "num_topic_categories > 128 not supported (loc = W U^T runs as one 128-wide column tile)");
   if (D > GDRF_DMAX) return fail(-1, "gdrf_ctx_create", "more than 4 input dimensions not supported");
   if (dtype != GDRF_F32 && dtype != GDRF_F64 && dtype != GDRF_F32_PURE) return fail(-1, "gdrf_ctx_create", "dtype");
   if (kernel_id < GDRF_RBF || kernel_id > GDRF_RATIONALQUADRATIC) return fail(-1, "gdrf_ctx_create", "kernel_id");
@@ -178,7 +184,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->ssz = dtype == GDRF_F32_PURE ? 4 : 8;
   c->nt = (c->Mp + GDRF_TILE - 1) / GDRF_TILE;
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
-  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->bf16x6 = 0;
+  c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->split = 0; c->wh_pieces = 0; c->ssc = nullptr; c->smx = nullptr;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0; c->mean = nullptr; c->mean_sk = c->mean_sn = 0;
   c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
@@ -222,11 +228,14 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->erows_grid_cap = 1024;
   AL(c->phibar_part, (size_t)c->erows_grid_cap * K * V * c->esz)
   const int64_t rtiles = (n_cap + GDRF_TILE - 1) / GDRF_TILE;
-  c->dpart_len = std::max<int64_t>(((rtiles + 8) * ((c->Mp + 63) / 64) + 16) * 3, 8192);
+  // users: bwd_knm 3 per workgroup, kuu_bar_reduce 3 per inducing point, elbo_rows 4 per workgroup, predict / ll_const <= 2 x 2048
+  c->dpart_len = std::max<int64_t>({((rtiles + 8) * ((c->Mp + 63) / 64) + 16) * 3, (int64_t)3 * c->Mp + 16, 4 * c->erows_grid_cap, (int64_t)8192});
   AL(c->dpart, (size_t)c->dpart_len * sizeof(double))
   AL(c->dsmall, 16 * sizeof(double))
+  AL(c->llpart, 2048 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
   AL(c->hyp, sizeof(Hyper)) AL(c->hyp_probe, sizeof(Hyper)) AL(c->flag, 64)
+  AL(c->ssc, (size_t)SplitLay{K}.nfloats() * sizeof(float)) AL(c->smx, (size_t)SplitLay{K}.nmax() * sizeof(unsigned))
 #undef AL
   HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact})
@@ -288,16 +297,17 @@ static int ws_lookup(gdrf_ctx* c, int which, void** ptr, int64_t* nelem, int* es
 int gdrf_ws_ptr(gdrf_ctx* c, int which, void** ptr, int64_t* nelem) { int e; return ws_lookup(c, which, ptr, nelem, &e); }
 int gdrf_stores_t(const gdrf_ctx* c) { return c->Tst != nullptr; }
 int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
-  if (mode != 0 && mode != 1) return fail(-1, "gdrf_set_mfma_mode", "mode");
-  if (mode == 1 && (c->esz != 4 || c->Tst)) return fail(-1, "gdrf_set_mfma_mode", "bf16x6 needs float arrays and the dense Wbar form");
+  if (mode < 0 || mode > 2) return fail(-1, "gdrf_set_mfma_mode", "mode");
+  if (mode != 0 && (c->esz != 4 || c->Tst)) return fail(-1, "gdrf_set_mfma_mode", "the split modes need float arrays and the dense Wbar form");
   HIPCHK(hipSetDevice(c->dev));
-  if (mode == 1 && !c->Wh) {          // bf16 pieces of W: 3 x n_cap x Mp halfwords, allocated on first use
+  const int np = mode == 1 ? 3 : (mode == 2 ? 2 : 0);
+  if (np > c->wh_pieces) {            // 16-bit pieces of W: np x n_cap x Mp halfwords, allocated on first use
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, (size_t)3 * c->ncap * c->Mp * 2);
+    hipError_t e = hipMalloc(&p, (size_t)np * c->ncap * c->Mp * 2);
     if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(Wh)", hipGetErrorString(e));
-    c->Wh = p; c->allocs.push_back(p);
+    c->Wh = p; c->wh_pieces = np; c->allocs.push_back(p);          // a smaller earlier block stays owned by the context until destroy
   }
-  c->bf16x6 = mode;
+  c->split = mode;
   return 0;
 }
 int gdrf_set_mean(gdrf_ctx* c, const void* mean, int64_t stride_k, int64_t stride_n) {
@@ -338,7 +348,7 @@ int gdrf_set_learn_inducing(gdrf_ctx* c, int on) {
   c->learn_z = on;
   return 0;
 }
-int gdrf_get_mfma_mode(const gdrf_ctx* c) { return c->bf16x6; }
+int gdrf_get_mfma_mode(const gdrf_ctx* c) { return c->split; }
 int gdrf_ws_elem_size(gdrf_ctx* c, int which) { void* p; int64_t n; int e; return ws_lookup(c, which, &p, &n, &e) ? -1 : e; }
 
 int gdrf_set_timing(gdrf_ctx* c, int enable) {
@@ -472,73 +482,93 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
-  // bf16 pieces of W and of S_k^T, then tt on the bf16 matrix path (f32 contexts only)
-  static int fwd_t_bf16x6(gdrf_ctx* c, int64_t n, int64_t rtiles, hipStream_t s) {
+  // block scales of the split modes (gemm_split.h): `what` = SPLIT_SC_* groups to refresh from hyp / the maxima
+  static void split_scales(gdrf_ctx* c, int what, hipStream_t s) {
+    hipLaunchKernelGGL(split_scales_kernel, dim3(1), dim3(64), 0, s, c->split == 2 ? 1 : 0, (const Hyper*)c->hyp, (const unsigned*)c->smx, c->ssc, c->K, what);
+  }
+
+  // pieces of S_k^T (and of W in the all-fp32 mode), then tt on the 16-bit matrix path (f32 contexts only)
+  template <class SP>
+  static int fwd_t_split(gdrf_ctx* c, int64_t n, int64_t rtiles, hipStream_t s) {
     if constexpr (std::is_same<T, float>::value) {
+      using E = typename SP::E;
       const int Mp = c->Mp, K = c->K;
+      const SplitLay SL{K};
       const int64_t nb = (int64_t)K * Mp * Mp, nw = n * Mp;
       {
         ScopedTimer tm(c, 2, s);
-        hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->ST, nb, Mp, Mp, (__bf16*)c->STh, nb);
+        hipLaunchKernelGGL(split_blocked_kernel<SP>, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->ST, nb, Mp, Mp, (E*)c->STh, nb,
+                           (const float*)c->ssc + SL.st(0));
         if (c->ssz != 8)       // with the f64 solve, fwd_w's epilogue has already written the pieces of W
-          hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((nw / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->W, nw, (__bf16*)c->Wh,
-                             (int64_t)c->ncap * Mp);
+          hipLaunchKernelGGL(split_kernel<SP>, dim3((unsigned)((nw / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->W, nw, (E*)c->Wh,
+                             (int64_t)c->ncap * Mp, (const float*)c->ssc + SL.w());
       }
       ScopedTimer tm(c, 5, s);
-      // topics per group: as many lower-triangular S^T piece panels (3 x ~0.6 Mp^2 halfwords each) as fit in 2 MB
-      const double panel = 0.625 * 6.0 * (double)Mp * Mp;
+      // topics per group: as many lower-triangular S^T piece panels (NP x ~0.6 Mp^2 halfwords each) as fit in 2 MB
+      const double panel = 0.625 * 2.0 * SP::NP * (double)Mp * Mp;
       const int KG = std::max(1, std::min(K, (int)(2.0 * 1024 * 1024 / panel)));
-      // two row tiles per 512-thread workgroup (two phase-shifted wave groups, LDS-DMA staging): 6 operand images of 24 KB
+      // two row tiles per 512-thread workgroup (two phase-shifted wave groups, LDS-DMA staging): 6 operand images
       const int64_t pairs = (rtiles + 1) / 2;
       const int rt8 = (int)((pairs + 7) / 8);
-      FwdTBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, rt8, (const __bf16*)c->STh, nb, (float*)c->tt, c->ldk};
-      constexpr int lds2 = 6 * 3 * Bf16x6Cfg::PIECE * 2;
-      HIPCHK(hipFuncSetAttribute((const void*)fwd_t_bf16x6_2g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-      hipLaunchKernelGGL(fwd_t_bf16x6_2g_kernel, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
-      LAUNCHCHK("fwd_t_bf16x6");
+      FwdTSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, rt8, (const E*)c->STh, nb, (float*)c->tt, c->ldk, (const float*)c->ssc};
+      constexpr int lds2 = 6 * SplitCfg<SP>::IMG * 2;
+      HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+      hipLaunchKernelGGL(fwd_t_split_2g_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
+      LAUNCHCHK("fwd_t_split");
       return 0;
     } else {
-      return fail(-1, "fwd_t_bf16x6", "float arrays only");
+      return fail(-1, "fwd_t_split", "float arrays only");
     }
   }
 
-  // C = Wh^T diag(scale) B over the observations on the bf16 matrix path (f32 contexts only); A side = the pieces of W
-  static int tn_bf16x6(gdrf_ctx* c, const float* B, const float* scale, int64_t scale_bs, int64_t n, int64_t rps, int sym, float* slab,
-                       int nbatch, int ns, int ntiles, hipStream_t s) {
+  // C = Wh^T diag(scale) B over the observations on the 16-bit matrix path (f32 contexts only); A side = the pieces of W.
+  // sidx_b / sidx_b_stride: SplitLay pair index of the B operand's block scale (per batch); b_is_w: B is the unscaled f32 W (A_k)
+  template <class SP>
+  static int tn_split(gdrf_ctx* c, const float* B, const float* scale, int64_t scale_bs, int64_t n, int64_t rps, int sym, float* slab,
+                      int nbatch, int ns, int ntiles, int sidx_b, int sidx_b_stride, int b_is_w, hipStream_t s) {
     if constexpr (std::is_same<T, float>::value) {
-      TNBf16Args a{(const __bf16*)c->Wh, (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns};
-      constexpr int lds = 3 * 3 * 32 * 128 * 2;                 // double-buffered A image + B image
-      HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL(gemm_tn_bf16x6_kernel, dim3((unsigned)(ntiles * nbatch * ns)), dim3(256), lds, s, a);
+      using E = typename SP::E;
+      TNSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns,
+                        (const float*)c->ssc, SplitLay{c->K}.w(), sidx_b, sidx_b_stride, b_is_w};
+      constexpr int lds = 3 * SP::NP * 32 * 128 * 2;            // double-buffered A image + B image
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_split_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(gemm_tn_split_kernel<SP>, dim3((unsigned)(ntiles * nbatch * ns)), dim3(256), lds, s, a);
       return 0;
     } else {
-      return fail(-1, "tn_bf16x6", "float arrays only");
+      return fail(-1, "tn_split", "float arrays only");
     }
   }
 
-  // Wbar on the bf16 matrix path (f32 contexts only)
-  static int wbar_bf16x6(gdrf_ctx* c, int64_t n, const T* U, int64_t rtiles, hipStream_t s) {
+  // Wbar on the 16-bit matrix path (f32 contexts only)
+  template <class SP>
+  static int wbar_split(gdrf_ctx* c, int64_t n, const T* U, int64_t rtiles, hipStream_t s) {
     if constexpr (std::is_same<T, float>::value) {
+      using E = typename SP::E;
       const int Mp = c->Mp, K = c->K;
+      const SplitLay SL{K};
       const int64_t nb = (int64_t)K * Mp * Mp;
-      hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, Mp, Mp, (__bf16*)c->Bh, nb);
-      BwdWbarBf16Args a{(const float*)c->W, (const __bf16*)c->Wh, (int64_t)c->ncap * Mp, n, c->M, Mp, K, (const __bf16*)c->Bh, nb,
-                        (const float*)c->vbar, (const float*)c->locbar, c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar};
-      const size_t grp = Bf16x6Cfg::LDS_BYTES + (((size_t)K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15);
+      hipLaunchKernelGGL(split_blocked_kernel<SP>, dim3((unsigned)((nb / 4 + 255) / 256)), dim3(256), 0, s, (const float*)c->Bm, nb, Mp, Mp, (E*)c->Bh, nb,
+                         (const float*)c->ssc + SL.b(0));
+      BwdWbarSplitArgs<SP> a{(const float*)c->W, (const E*)c->Wh, (int64_t)c->ncap * Mp, n, c->M, Mp, K, (const E*)c->Bh, nb,
+                             (const float*)c->vbar, (const float*)c->locbar, c->ldk, (const float*)c->asum, (const float*)U, (float*)c->Wbar,
+                             (const float*)c->ssc, c->smx + SL.mx_wbar()};
+      const size_t grp = SplitCfg<SP>::LDS_BYTES + (((size_t)K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15);
       const int nct_ = (Mp + GDRF_TILE - 1) / GDRF_TILE;
       if (K >= 2 && 2 * grp <= 160 * 1024) {   // two phase-shifted wave groups per workgroup (own A images, shared double-buffered B, LDS-DMA staging)
         const int64_t pairs = (rtiles + 1) / 2;
-        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * grp)));
-        hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel<2>, dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), 2 * grp, s, a);
+        const size_t lds = std::max<size_t>(2 * grp, 8 * 32 * 68 * sizeof(float));      // the epilogue's transposition tiles
+        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_kernel<SP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((bwd_wbar_split_kernel<SP, 2>), dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds, s, a);
       } else {
-        if (grp > 160 * 1024) return fail(-1, "wbar_bf16x6", "too many topics for the LDS scale table");
-        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_bf16x6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grp));
-        hipLaunchKernelGGL(bwd_wbar_bf16x6_kernel<1>, dim3((unsigned)round_up(rtiles * nct_, 8)), dim3(256), grp, s, a);
+        if (grp > 160 * 1024) return fail(-1, "wbar_split", "too many topics for the LDS scale table");
+        const size_t lds = std::max<size_t>(grp, 4 * 32 * 68 * sizeof(float));
+        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_kernel<SP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((bwd_wbar_split_kernel<SP, 1>), dim3((unsigned)round_up(rtiles * nct_, 8)), dim3(256), lds, s, a);
       }
-      LAUNCHCHK("wbar_bf16x6");
+      LAUNCHCHK("wbar_split");
       return 0;
     } else {
-      return fail(-1, "wbar_bf16x6", "float arrays only");
+      return fail(-1, "wbar_split", "float arrays only");
     }
   }
 
@@ -590,6 +620,17 @@ template <typename T, typename TS> struct Impl {
       }
       hipLaunchKernelGGL(build_upad_kernel<T>, dim3((Mp + 255) / 256, GDRF_TILE), dim3(256), 0, s, U, K, M, Mp, P(c->Upad));
       if (!c->Tst && (rc = mm_nt<T>(c, P(c->S), mm, P(c->S), mm, P(c->Bm), mm, T(1), K, s))) return rc;      // B_k = S_k S_k^T
+      if constexpr (std::is_same<T, float>::value) {
+        if (c->split) {            // block scales of W (from the variance), B_k and S_k^T (from their maxima)
+          const SplitLay SL{K};
+          HIPCHK(hipMemsetAsync(c->smx, 0, (size_t)SL.nmax() * sizeof(unsigned), s));
+          if (c->split == 2) {
+            hipLaunchKernelGGL(absmax_batched_kernel, dim3(64, K), dim3(256), 0, s, (const float*)c->Bm, mm, mm, c->smx + SL.mx_b(0));
+            hipLaunchKernelGGL(absmax_batched_kernel, dim3(64, K), dim3(256), 0, s, (const float*)c->ST, mm, mm, c->smx + SL.mx_st(0));
+          }
+          split_scales(c, SPLIT_SC_W | SPLIT_SC_BST, s);
+        }
+      }
     }
     const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
     // (1) W = Knm Linv^T in the solve precision, stored in the N-side precision
@@ -598,7 +639,9 @@ template <typename T, typename TS> struct Impl {
       if ((rc = join_fact(c, s))) return rc;          // W needs L^-1
       ScopedTimer tm(c, 3, s);
       FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
-      if (c->bf16x6 && sizeof(TS) == 8 && sizeof(T) == 4) { p.Wh = (__bf16*)c->Wh; p.wh_stride = (int64_t)c->ncap * Mp; }   // pieces of W from the same epilogue
+      if (c->split && sizeof(TS) == 8 && sizeof(T) == 4) {      // pieces of W from the same epilogue
+        p.Wh = c->Wh; p.wh_stride = (int64_t)c->ncap * Mp; p.wh_mode = c->split; p.wh_scale = c->ssc + SplitLay{K}.w();
+      }
       hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
     }
     // loc = W U^T, on the side stream beside fwd_t (both only read W)
@@ -611,8 +654,8 @@ template <typename T, typename TS> struct Impl {
     }
     HIPCHK(hipEventRecord(c->ev_loc, c->side));
     // (2) tt_kn = ||S_k^T w_n||^2
-    if (c->bf16x6) {
-      if ((rc = fwd_t_bf16x6(c, n, rtiles, s))) return rc;
+    if (c->split) {
+      if ((rc = (c->split == 2 ? fwd_t_split<SplitF16>(c, n, rtiles, s) : fwd_t_split<SplitBf16>(c, n, rtiles, s)))) return rc;
     } else {
       ScopedTimer tm(c, 5, s);
       FwdTProb<T> p{{K}, {}, {}, P(c->W), n, Mp, P(c->ST), P(c->tt), ldk, P(c->Tst), c->t_bs, c->t_ts};
@@ -624,20 +667,37 @@ template <typename T, typename TS> struct Impl {
     int egrid;
     {
       ScopedTimer tm(c, 6, s);
+      const bool kreg = K <= GDRF_KMAX;
+      auto lds_for = [&](int rb) {
+        return 128 + ((size_t)2 * K * V + (size_t)rb * (K + 1) * (kreg ? 1 : 2) + (size_t)rb * (V + 1)) * sizeof(T);
+      };
       int RB = 128;
-      size_t lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T);
-      if (lds > 150 * 1024) { RB = 64; lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T); }
-      if (lds > 150 * 1024) return fail(-1, "gdrf_step_local", "K*V too large for the row kernel's LDS budget");
-      if (lds > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)elbo_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      while (RB > 32 && lds_for(RB) > 150 * 1024) RB >>= 1;
+      const size_t lds = lds_for(RB);
+      if (lds > 150 * 1024)
+        return fail(-1, "gdrf_step_local", "num_topic_categories x num_observation_categories too large: the row kernel keeps the "
+                                           "(K, V) word-topic matrix and its gradient in LDS (2*K*V + 32*(2K + V + 3) elements <= 150 KB)");
+      const void* kfn = kreg ? (const void*)elbo_rows_kernel<T, true> : (const void*)elbo_rows_kernel<T, false>;
+      if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t nblk = (n + RB - 1) / RB;
       egrid = (int)std::min<int64_t>(nblk, c->erows_grid_cap);
-      hipLaunchKernelGGL(elbo_rows_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
-                         ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+      if (kreg)
+        hipLaunchKernelGGL((elbo_rows_kernel<T, true>), dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
+                           ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+      else
+        hipLaunchKernelGGL((elbo_rows_kernel<T, false>), dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
+                           ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
       LAUNCHCHK("elbo_rows");
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
                          (int64_t)K * V, redT + roff(c, 1));
+      if constexpr (std::is_same<T, float>::value) {
+        if (c->split) {            // block scale of diag(vbar_k) W, the scaled operand of the A_k contraction
+          if (c->split == 2)
+            hipLaunchKernelGGL(absmax_batched_kernel, dim3(64, K), dim3(256), 0, s, (const float*)c->vbar, n, ldk, c->smx + SplitLay{K}.mx_v(0));
+          split_scales(c, SPLIT_SC_V, s);
+        }
+      }
     }
     // (3) Wbar
     {
@@ -650,8 +710,9 @@ template <typename T, typename TS> struct Impl {
         if (lds > 48 * 1024)
           HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BwdWbarTProb<T>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((gemm_nt_kernel<T, BwdWbarTProb<T>>), grid, dim3(256), lds, s, p);
-      } else if (c->bf16x6) {
-        if ((rc = wbar_bf16x6(c, n, U, rtiles, s))) return rc;
+      } else if (c->split) {
+        if ((rc = (c->split == 2 ? wbar_split<SplitF16>(c, n, U, rtiles, s) : wbar_split<SplitBf16>(c, n, U, rtiles, s)))) return rc;
+        split_scales(c, SPLIT_SC_WBAR, s);           // max |Wbar| came out of the epilogue: scale of the G^T contraction's operand
       } else {
         BwdWbarProb<T> p{{}, {}, P(c->W), n, M, Mp, K, P(c->Bm), P(c->vbar), P(c->locbar), ldk, P(c->asum), U, P(c->Wbar)};
         if (lds > 48 * 1024)
@@ -666,13 +727,15 @@ template <typename T, typename TS> struct Impl {
     {
       hipStream_t ss = c->side;
       const int BR = TNCfg<T>::BR;
-      const int ns = std::min(c->bf16x6 ? tn_nsplit_gt(c, n, BR) : tn_nsplit(c, n, BR, 3), c->nsplit_cap);
+      const int ns = std::min(c->split ? tn_nsplit_gt(c, n, BR) : tn_nsplit(c, n, BR, 3), c->nsplit_cap);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
       T* slab_gt = P(c->slab) + (int64_t)c->nsplit_cap * K * mm;           // the (K+1)-th batch region of the slab buffer
       TNArgs<T> b{P(c->W), Mp, P(c->Wbar), Mp, nullptr, 0, n, rps, Mp, 0, slab_gt, 1, ns};
       { ScopedTimer tm(c, 10, ss);
-        if (c->bf16x6) {
-          if ((rc = tn_bf16x6(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ss))) return rc;
+        if (c->split) {
+          const int ib = SplitLay{K}.wbar();
+          if ((rc = (c->split == 2 ? tn_split<SplitF16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ib, 0, 0, ss)
+                                   : tn_split<SplitBf16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ib, 0, 0, ss)))) return rc;
         } else {
           hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, ss, b);
         } }
@@ -713,12 +776,14 @@ template <typename T, typename TS> struct Impl {
     // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
     {
       const int BR = TNCfg<T>::BR;
-      const int ns = std::min(tn_nsplit(c, n, BR, c->bf16x6 ? 2 : 3), c->nsplit_cap);
+      const int ns = std::min(tn_nsplit(c, n, BR, c->split ? 2 : 3), c->nsplit_cap);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
       TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K, ns};
       { ScopedTimer tm(c, 9, s);
-        if (c->bf16x6) {
-          if ((rc = tn_bf16x6(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, c->nt * (c->nt + 1) / 2, s))) return rc;
+        if (c->split) {
+          const int ib = SplitLay{K}.v(0), ntl = c->nt * (c->nt + 1) / 2;
+          if ((rc = (c->split == 2 ? tn_split<SplitF16>(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, ntl, ib, 2, 1, s)
+                                   : tn_split<SplitBf16>(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, ntl, ib, 2, 1, s)))) return rc;
         } else {
           hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * (c->nt + 1) / 2 * K * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, a);
         } }
@@ -795,15 +860,25 @@ template <typename T, typename TS> struct Impl {
     }
     if (mode >= 2) hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, params + poff(c, 4), K, V, P(c->phi));
     hipLaunchKernelGGL((predict_coeff_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, K, Q(c->Cf));
-    size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(TS);
-    int in_lds = 1;
-    if (lds > 64 * 1024) { in_lds = 0; lds -= (size_t)K * M * sizeof(TS); }
-    if (lds > 48 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)predict_rows_kernel<TS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = (n + 127) / 128; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     const int64_t ldo = mode == 0 ? n : (mode == 1 ? K : V);
-    hipLaunchKernelGGL((predict_rows_kernel<TS, T>), dim3((unsigned)blocks), dim3(128), lds, s, X, n, (const TS*)Q(c->Zs), M, c->D, c->kind,
-                       c->hyp, (const TS*)Q(c->Cf), K, V, (const T*)P(c->phi), ws, mode, out, ldo, c->dpart, in_lds);
+    if (K > GDRF_KMAX) {
+      const size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)128 * (V + 1)) * sizeof(TS);
+      if (lds > 150 * 1024) return fail(-1, "gdrf_predict", "M*D + K*V + 128*(V+1) solve-precision elements exceed the LDS budget (150 KB)");
+      if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)predict_rows_bigk_kernel<TS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((predict_rows_bigk_kernel<TS, T>), dim3((unsigned)blocks), dim3(128), lds, s, X, n, (const TS*)Q(c->Zs), M, c->D, c->kind,
+                         c->hyp, (const TS*)Q(c->Cf), K, V, (const T*)P(c->phi), ws, mode, out, ldo, c->dpart);
+    } else {
+      size_t lds = 128 + ((size_t)M * c->D + (size_t)K * V + (size_t)K * M) * sizeof(TS);
+      int in_lds = 1;
+      if (lds > 64 * 1024) { in_lds = 0; lds -= (size_t)K * M * sizeof(TS); }
+      if (lds > 150 * 1024) return fail(-1, "gdrf_predict", "M*D + K*V solve-precision elements exceed the LDS budget (150 KB)");
+      if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)predict_rows_kernel<TS, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((predict_rows_kernel<TS, T>), dim3((unsigned)blocks), dim3(128), lds, s, X, n, (const TS*)Q(c->Zs), M, c->D, c->kind,
+                         c->hyp, (const TS*)Q(c->Cf), K, V, (const T*)P(c->phi), ws, mode, out, ldo, c->dpart, in_lds);
+    }
     if (mode == 3) hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, blocks, 2, out_d);
     LAUNCHCHK("predict");
     return 0;
@@ -828,13 +903,37 @@ int gdrf_fill_eps(gdrf_ctx* c, uint64_t seed, uint32_t step, int64_t n_offset, i
   return 0;
 }
 
-int gdrf_ll_const(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_host, void* stream) {
+// red_d (8 + M*D doubles) -> tail of red_T, and back after the all-reduce
+int gdrf_payload_pack(gdrf_ctx* c, void* redT, const double* redd, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  const int nd = 8 + c->M * c->D;
+  if (c->esz == 8) hipLaunchKernelGGL(payload_pack_kernel<double>, dim3((nd + 255) / 256), dim3(256), 0, (hipStream_t)stream, redd, nd, (double*)redT + roff(c, 5));
+  else hipLaunchKernelGGL(payload_pack_kernel<float>, dim3((nd + 255) / 256), dim3(256), 0, (hipStream_t)stream, redd, nd, (float*)redT + roff(c, 5));
+  LAUNCHCHK("payload_pack");
+  return 0;
+}
+int gdrf_payload_unpack(gdrf_ctx* c, const void* redT, double* redd, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  const int nd = 8 + c->M * c->D;
+  if (c->esz == 8) hipLaunchKernelGGL(payload_unpack_kernel<double>, dim3((nd + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)redT + roff(c, 5), nd, redd);
+  else hipLaunchKernelGGL(payload_unpack_kernel<float>, dim3((nd + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)redT + roff(c, 5), nd, redd);
+  LAUNCHCHK("payload_unpack");
+  return 0;
+}
+
+int gdrf_ll_const_dev(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_dev, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(ll_const_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, n, c->V, c->dpart);
-  hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, blocks, 1, c->dsmall + 8);
+  hipLaunchKernelGGL(ll_const_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, n, c->V, c->llpart);
+  hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->llpart, blocks, 1, out_dev);
   LAUNCHCHK("ll_const");
+  return 0;
+}
+
+int gdrf_ll_const(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_host, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = gdrf_ll_const_dev(c, ws, n, c->dsmall + 8, stream)) return rc;
   HIPCHK(hipMemcpyAsync(out_host, c->dsmall + 8, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return 0;

@@ -1,112 +1,222 @@
-// The f32 GEMM-shaped contractions of the step on the bf16 matrix path with exact-split emulation ("bf16x6").
+// The f32 GEMM-shaped contractions of the step on the 16-bit matrix path with split-operand emulation.
 //
-// gfx950 runs f32-input MFMA at 1/16 of the bf16 rate (MI355X_MICROARCH.md: 157 TF vs ~2.5 PF), and ~90 % of the step is
-// bound by it.  Here every f32 operand x is written as x = x1 + x2 + x3 with bf16 pieces (x1 = bf16(x), x2 = bf16(x - x1),
-// x3 = bf16(x - x1 - x2): 3 x 8 significand bits, residual <= 2^-24 |x|), and a product a*b is the sum of the SIX cross
-// terms of weight >= 2^-16:  a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1).  The dropped terms are <= 2^-24 |ab|, i.e. the
-// rounding of one f32 product, so the result has f32-level error while running on mfma_f32_16x16x32_bf16 with f32
-// accumulation (16/6 = 2.7x the f32 MFMA rate).  Measured against fp64 products of the same inputs the emulated kernels are
-// as close as, or closer than, the native f32 MFMA ones (tests/test_gpu_parity.py::test_bf16x6_against_fp64_product...).
+// gfx950 runs f32-input MFMA at 1/16 of the bf16 / f16 rate (MI355X_MICROARCH.md: 157 TF vs ~2.5 PF), and ~85 % of the step
+// is bound by it.  Every f32 operand is written as a short sum of 16-bit pieces and a product a*b as the sum of the cross
+// terms that matter, accumulated in f32 by v_mfma_f32_16x16x32_{f16,bf16}.  Two policies:
 //
-//   split3_kernel            W, B_k = S_k S_k^T and S_k^T -> 3 bf16 pieces each, once per step
-//   bwd_wbar_bf16x6_kernel   Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W   (replaces gemm_nt<BwdWbarProb>)
-//   fwd_t_bf16x6_2g_kernel   tt[k][n] = |S_k^T w_n|^2                                           (replaces gemm_nt<FwdTProb>)
-//   gemm_tn_bf16x6_kernel    A_k = W^T diag(vbar_k) W  and  GT = W^T Wbar                        (replaces gemm_tn_kernel<float>)
+//   SplitF16  ("f16x3", default): x 2^e = h + l with fp16 pieces (h = f16(y), l = f16(y - h): 11 + 11 significand bits and the
+//             sign of the residual, |y - h - l| <= 2^-23 |y|), products hh + hl + lh; the dropped ll term is <= 2^-22 |ab| and
+//             random in sign.  fp16 has 5 exponent bits, so every operand carries ONE power-of-two block scale 2^e that puts its
+//             largest magnitude just below 2^15 (bound known: |W| <= sqrt(variance); measured: max |B_k|, max |S_k|, max |vbar_k|,
+//             max |Wbar|, by order-independent integer atomicMax); elements down to 2^-18 of the block maximum keep the full 22
+//             bits, smaller ones an ABSOLUTE error of 2^-40 of the maximum - negligible in a sum whose f32 accumulation already
+//             rounds at 2^-24 of the running total.  The scales are exact (powers of two) and undone in the epilogues.
+//             3 MFMAs per f32 multiply-add: 16/3 = 5.3x the f32 MFMA rate, and 3 (not 6 or 32) accumulator roundings per 32
+//             reduction indices.
+//   SplitBf16 ("bf16x6"): x = x1 + x2 + x3 with bf16 pieces (3 x 8 bits, exact to 2^-24 |x|, f32's exponent range, no scaling),
+//             the six cross terms of weight >= 2^-16.  2.7x the f32 MFMA rate.  Kept selectable (mfma_mode).
+//
+// Both are held to the error of the native f32 MFMA kernels on the same inputs, measured against fp64 products
+// (tests/test_gpu_parity.py::test_split_modes_against_fp64_product_of_the_same_inputs).
+//
+//   split_kernel / split_blocked_kernel   W, B_k = S_k S_k^T and S_k^T -> pieces, once per step (W's come from fwd_w's epilogue)
+//   bwd_wbar_split_kernel    Wbar = sum_k diag(2 vbar_k) W B_k + locbar^T U - 2 diag(asum) W   (replaces gemm_nt<BwdWbarProb>)
+//   fwd_t_split_2g_kernel    tt[k][n] = |S_k^T w_n|^2                                           (replaces gemm_nt<FwdTProb>)
+//   gemm_tn_split_kernel     A_k = W^T diag(vbar_k) W  and  GT = W^T Wbar                        (replaces gemm_tn_kernel<float>)
 //
 // All keep the tiling, block maps, deterministic slab reduction and epilogues of the f32 forms they replace.
 #pragma once
 #include "common.h"
 #include "gemm_nt.h"
+#include "kernels_mm.h"
 
 namespace gdrf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-struct Bf16x6Cfg {
+struct SplitBf16 {
+  using E = __bf16; using V8 = bf16x8; using V4 = bf16x4;
+  static constexpr int NP = 3, NPROD = 6, ID = 1;
+  // cross products (piece of A, piece of B), smallest weight first
+  static __device__ __forceinline__ constexpr int pa(int t) { constexpr int v[6] = {0, 1, 2, 0, 1, 0}; return v[t]; }
+  static __device__ __forceinline__ constexpr int pb(int t) { constexpr int v[6] = {2, 1, 0, 1, 0, 0}; return v[t]; }
+  static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(float x, E (&p)[NP]) {
+    p[0] = (__bf16)x;
+    const float r1 = x - (float)p[0];
+    p[1] = (__bf16)r1;
+    p[2] = (__bf16)(r1 - (float)p[1]);
+  }
+};
+struct SplitF16 {
+  using E = _Float16; using V8 = f16x8; using V4 = f16x4;
+  static constexpr int NP = 2, NPROD = 3, ID = 2;
+  static __device__ __forceinline__ constexpr int pa(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
+  static __device__ __forceinline__ constexpr int pb(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
+  static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(float y, E (&p)[NP]) {     // y = x * block scale
+    p[0] = (_Float16)y;
+    p[1] = (_Float16)(y - (float)p[0]);
+  }
+};
+
+// ---- block scales -------------------------------------------------------------------------------------------------
+// Device float array of (scale, 1 / scale) pairs and the unsigned array of maxima (bit patterns of non-negative floats, which
+// order like the floats) they come from.  SplitBf16 runs with every scale = 1.
+struct SplitLay {
+  int K;
+  __host__ __device__ int w() const { return 0; }                    // W: from the bound |W| <= sqrt(variance)
+  __host__ __device__ int wbar() const { return 2; }
+  __host__ __device__ int b(int k) const { return 4 + 2 * k; }
+  __host__ __device__ int st(int k) const { return 4 + 2 * K + 2 * k; }
+  __host__ __device__ int v(int k) const { return 4 + 4 * K + 2 * k; }
+  __host__ __device__ int nfloats() const { return 4 + 6 * K; }
+  __host__ __device__ int mx_wbar() const { return 0; }
+  __host__ __device__ int mx_b(int k) const { return 1 + k; }
+  __host__ __device__ int mx_st(int k) const { return 1 + K + k; }
+  __host__ __device__ int mx_v(int k) const { return 1 + 2 * K + k; }
+  __host__ __device__ int nmax() const { return 1 + 3 * K; }
+};
+// power of two s with bound * s in [2^(top-1), 2^top)
+__device__ __forceinline__ float split_pow2_scale(float bound, int top) {
+  if (!(bound > 0.0f) || !(bound < 3.0e38f)) return 1.0f;
+  int ex;
+  (void)frexpf(bound, &ex);                 // bound = m 2^ex, m in [0.5, 1)
+  int e = top - ex;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+enum { SPLIT_SC_W = 1, SPLIT_SC_BST = 2, SPLIT_SC_V = 4, SPLIT_SC_WBAR = 8 };
+// what: which groups to (re)compute.  f16 = 0 writes ones.
+__global__ void split_scales_kernel(int f16, const Hyper* __restrict__ h, const unsigned* __restrict__ mx, float* __restrict__ sc, int K, int what) {
+  const SplitLay L{K};
+  auto put = [&](int idx, float s) { sc[idx] = s; sc[idx + 1] = 1.0f / s; };
+  const int t = threadIdx.x;
+  if ((what & SPLIT_SC_W) && t == 0)          // |w_nj| <= ||w_n|| <= sqrt(k(x,x)) = sqrt(variance); 4x headroom for rounding in the solve
+    put(L.w(), f16 ? split_pow2_scale(sqrtf((float)h->var), 13) : 1.0f);
+  if ((what & SPLIT_SC_WBAR) && t == 0) put(L.wbar(), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_wbar()]), 15) : 1.0f);
+  for (int k = t; k < K; k += blockDim.x) {
+    if (what & SPLIT_SC_BST) {
+      put(L.b(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_b(k)]), 15) : 1.0f);
+      put(L.st(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_st(k)]), 15) : 1.0f);
+    }
+    if (what & SPLIT_SC_V) put(L.v(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_v(k)]), 15) : 1.0f);
+  }
+}
+// mx[b] = max |x[b][i]|, i < n (grid: (blocks, batches)); mx zeroed by the caller
+__global__ __launch_bounds__(256) void absmax_batched_kernel(const float* __restrict__ x, int64_t n, int64_t ld, unsigned* __restrict__ mx) {
+  const int b = blockIdx.y;
+  float m = 0;
+  const f32x4* p = reinterpret_cast<const f32x4*>(x + (int64_t)b * ld);          // ld a multiple of 4
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = p[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(int64_t)b * ld + (n & ~(int64_t)3) + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(mx + b, __float_as_uint(m));
+}
+
+template <class SP> struct SplitCfg {
   static constexpr int BK = 32;                 // f32 reduction indices per chunk = one 16x16x32 MFMA deep
   static constexpr int LDH = BK;                // LDS row = 32 halfwords = 64 bytes = four 16-byte quads, no padding
   static constexpr int PIECE = GDRF_TILE * LDH; // halfwords per piece image of a 128-row operand tile
-  static constexpr int LDS_BYTES = 2 * 3 * PIECE * 2;    // A and B, 3 pieces each: 49152
+  static constexpr int IMG = SP::NP * PIECE;    // halfwords per operand image
+  static constexpr int LDS_BYTES = 2 * IMG * 2; // A and B images
 };
 // LDS image of an operand tile: element (row, k) lives at halfword  row*32 + ((k>>3) ^ swz(row))*8 + (k&7), swz(row) = 3 if
 // (row & 8) else 0.  ds_read_b128 serves a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... with bank =
 // dword mod 64 (MI355X_MICROARCH.md, LDS): an MFMA fragment read (lane -> row lane&15, quad lane>>4) then touches, in every
 // group, all 16 (row mod 4, physical quad) pairs exactly once - conflict-free; a padded 80-byte row is not (measured: 47 %
 // of the LDS cycles were bank conflicts).  ds_write_b128 (8 contiguous lanes = 2 whole rows = 32 distinct banks) is too.
-__device__ __forceinline__ int bf16x6_swz(int row) { return (row & 8) ? 3 : 0; }
-__device__ __forceinline__ int bf16x6_off(int row, int k) { return row * 32 + (((k >> 3) ^ bf16x6_swz(row)) << 3) + (k & 7); }
+__device__ __forceinline__ int split_swz(int row) { return (row & 8) ? 3 : 0; }
+__device__ __forceinline__ int split_off(int row, int k) { return row * 32 + (((k >> 3) ^ split_swz(row)) << 3) + (k & 7); }
 
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)x;
-  const float r1 = x - (float)h;
-  m = (__bf16)r1;
-  l = (__bf16)(r1 - (float)m);
-}
-
-// out[p * stride + i] = p-th bf16 piece of in[i]; 4 elements per thread (n multiple of 4)
-__global__ void split3_kernel(const float* __restrict__ in, int64_t n, __bf16* __restrict__ out, int64_t stride) {
+// out[p * stride + i] = p-th piece of in[i] * scale; 4 elements per thread (n multiple of 4)
+template <class SP>
+__global__ void split_kernel(const float* __restrict__ in, int64_t n, typename SP::E* __restrict__ out, int64_t stride, const float* __restrict__ scale) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
+  const float s = scale[0];
   const f32x4 x = *reinterpret_cast<const f32x4*>(in + i);
-  bf16x4 h, m, l;
+  typename SP::V4 pv[SP::NP];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(x[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
-  *reinterpret_cast<bf16x4*>(out + i) = h;
-  *reinterpret_cast<bf16x4*>(out + stride + i) = m;
-  *reinterpret_cast<bf16x4*>(out + 2 * stride + i) = l;
+  for (int e = 0; e < 4; ++e) {
+    typename SP::E p[SP::NP];
+    SP::split(x[e] * s, p);
+#pragma unroll
+    for (int q = 0; q < SP::NP; ++q) pv[q][e] = p[q];
+  }
+#pragma unroll
+  for (int q = 0; q < SP::NP; ++q) *reinterpret_cast<typename SP::V4*>(out + q * stride + i) = pv[q];
 }
 
 // the same pieces in k-blocked order for the NT kernels' small operands (B_k, S_k^T):  in[b][r][c] (b < nb, r < R, c < C, C a
-// multiple of 32)  ->  out[p][b][c / 32][r][c % 32].  A tile's 32-wide reduction chunk is then ONE contiguous block of whole
-// 128-byte lines (rows x 64 B), instead of 64 B out of every 1 KB row: the row-major form left the load path saturated
-// (measured: ~4000 cycles per prefetched load, 1500 of every 4600 cycles per chunk spent waiting for them).
-__global__ void split3_blocked_kernel(const float* __restrict__ in, int64_t n, int R, int C, __bf16* __restrict__ out, int64_t stride) {
+// multiple of 32)  ->  out[p][b][c / 32][r][c % 32], batch b scaled by scale[2 b].  A tile's 32-wide reduction chunk is then ONE
+// contiguous block of whole 128-byte lines (rows x 64 B), instead of 64 B out of every 1 KB row: the row-major form left the
+// load path saturated (measured: ~4000 cycles per prefetched load, 1500 of every 4600 cycles per chunk spent waiting for them).
+template <class SP>
+__global__ void split_blocked_kernel(const float* __restrict__ in, int64_t n, int R, int C, typename SP::E* __restrict__ out, int64_t stride,
+                                     const float* __restrict__ scale) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  const f32x4 x = *reinterpret_cast<const f32x4*>(in + i);
-  bf16x4 h, m, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(x[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
   const int64_t rc = (int64_t)R * C, b = i / rc, rem = i - b * rc;
+  const float s = scale[2 * b];
+  const f32x4 x = *reinterpret_cast<const f32x4*>(in + i);
+  typename SP::V4 pv[SP::NP];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    typename SP::E p[SP::NP];
+    SP::split(x[e] * s, p);
+#pragma unroll
+    for (int q = 0; q < SP::NP; ++q) pv[q][e] = p[q];
+  }
   const int r = (int)(rem / C), c = (int)(rem - (int64_t)r * C);
   const int64_t o = b * rc + ((int64_t)(c >> 5) * R + r) * 32 + (c & 31);
-  *reinterpret_cast<bf16x4*>(out + o) = h;
-  *reinterpret_cast<bf16x4*>(out + stride + o) = m;
-  *reinterpret_cast<bf16x4*>(out + 2 * stride + o) = l;
+#pragma unroll
+  for (int q = 0; q < SP::NP; ++q) *reinterpret_cast<typename SP::V4*>(out + q * stride + o) = pv[q];
 }
 
-struct BwdWbarBf16Args {
-  const float* W; const __bf16* Wh; int64_t w_stride;   // W (f32, epilogue) and its 3 bf16 pieces [p][row][Mp]
+template <class SP> struct BwdWbarSplitArgs {
+  const float* W; const typename SP::E* Wh; int64_t w_stride;   // W (f32, epilogue) and its pieces [p][row][Mp]
   int64_t nrows; int M, Mp, K;
-  const __bf16* Bh; int64_t piece_stride;     // Bh[p][k][i / 32][col][i % 32] (k-blocked), piece_stride = K*Mp*Mp
+  const typename SP::E* Bh; int64_t piece_stride;     // Bh[p][k][i / 32][col][i % 32] (k-blocked), piece_stride = K*Mp*Mp
   const float* vbar; const float* locbar; int64_t ldk;
   const float* asum; const float* U; float* Wbar;
+  const float* sc;                             // block scales (SplitLay)
+  unsigned* wbar_max;                          // max |Wbar| (bits), for the scale of the G^T contraction's operand
 };
 
 // NG = 1: one 256-thread workgroup per tile, two workgroups per CU (they share the CU's SIMDs at random).
 // NG = 2: one 512-thread workgroup per CU holding TWO such tiles, one per wave group (waves 0-3 / 4-7: a workgroup's waves
 // go to the SIMDs cyclically, so every SIMD hosts one wave of each group), run phase-shifted on purpose: in every phase one
-// group multiplies its staged chunk while the other moves its next chunk from registers to LDS and issues the loads of the
-// one after, then they swap.  Measured cause (s_memtime per wave, NG = 1): the multiply phase is 1810 cycles (MFMA 1536) but
-// every wave then waits ~1500 cycles at the barrier - each SIMD's two waves contend for the matrix pipe at random and the
-// barrier paces a workgroup by its unluckiest wave.  With the groups alternating, the multiplying wave has its SIMD's pipe
-// to itself and the staging hides behind it.  The phase barrier is a raw s_barrier after s_waitcnt lgkmcnt(0): a
-// __syncthreads() would also drain vmcnt and wait for the prefetch just issued.
-template <int NG>
-__global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf16Args g) {
-  using CF = Bf16x6Cfg;
+// group multiplies its staged chunk while the other issues the LDS-DMA loads of the one after, then they swap.  Measured
+// cause (s_memtime per wave, NG = 1): the multiply phase is 1810 cycles (MFMA 1536) but every wave then waits ~1500 cycles at
+// the barrier - each SIMD's two waves contend for the matrix pipe at random and the barrier paces a workgroup by its
+// unluckiest wave.  With the groups alternating, the multiplying wave has its SIMD's pipe to itself and the staging hides
+// behind it.  The phase barrier is a raw s_barrier after s_waitcnt lgkmcnt(0): a __syncthreads() would also drain vmcnt and
+// wait for the prefetch just issued.
+template <class SP, int NG>
+__global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_split_kernel(BwdWbarSplitArgs<SP> g) {
+  using CF = SplitCfg<SP>;
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  constexpr int NP = SP::NP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int gp = NG == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
   // LDS: NG = 1: [A][B][scale];  NG = 2: [A of group 0][A of group 1][B buffer 0][B buffer 1][scale 0][scale 1] - the two
   // groups work on the same column tile, so the B chunk is staged ONCE (by group 1) into a double-buffered image both read
-  constexpr int IMG = 3 * CF::PIECE;                          // halfwords per operand image
+  constexpr int IMG = CF::IMG;
   const size_t tab = ((size_t)g.K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15;
-  __bf16* As = reinterpret_cast<__bf16*>(smem) + (NG == 2 ? gp * IMG : 0);              // [3][128][LDH]
-  __bf16* Bs = reinterpret_cast<__bf16*>(smem) + (NG == 2 ? 2 * IMG : IMG);             // [NG][3][128][LDH]
-  float* scaleS = reinterpret_cast<float*>(smem + (size_t)(NG == 2 ? 4 : 2) * IMG * 2 + (size_t)gp * tab);  // [K][128]  2 vbar_kn
+  E* As = reinterpret_cast<E*>(smem) + (NG == 2 ? gp * IMG : 0);              // [NP][128][LDH]
+  E* Bs = reinterpret_cast<E*>(smem) + (NG == 2 ? 2 * IMG : IMG);             // [NG][NP][128][LDH]
+  float* scaleS = reinterpret_cast<float*>(smem + (size_t)(NG == 2 ? 4 : 2) * IMG * 2 + (size_t)gp * tab);  // [K][128]  2 vbar_kn / (sW sB_k)
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
@@ -128,12 +238,16 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
   const int64_t m0 = rtile * GDRF_TILE;
   const int n0 = ct * GDRF_TILE;
   const int K = g.K, Mp = g.Mp;
+  const SplitLay SL{K};
 
-  for (int e = tid; e < K * GDRF_TILE; e += 256) {
-    const int k = e / GDRF_TILE, r = e - k * GDRF_TILE;
-    scaleS[e] = (m0 + r < g.nrows) ? 2.0f * g.vbar[(int64_t)k * g.ldk + m0 + r] : 0.0f;
+  {
+    const float unw = g.sc[SL.w() + 1];
+    for (int e = tid; e < K * GDRF_TILE; e += 256) {
+      const int k = e / GDRF_TILE, r = e - k * GDRF_TILE;
+      scaleS[e] = (m0 + r < g.nrows) ? 2.0f * g.vbar[(int64_t)k * g.ldk + m0 + r] * (unw * g.sc[SL.b(k) + 1]) : 0.0f;
+    }
   }
-  // staging map, both operands: per piece 2 x 16-byte vectors of 8 bf16 per thread (vector v = tid + 256 j: row v>>2,
+  // staging map, both operands: per piece 2 x 16-byte vectors of 8 halfwords per thread (vector v = tid + 256 j: row v>>2,
   // k offset 8*(v&3))
   f32x4 acc[4][4];
 #pragma unroll
@@ -141,7 +255,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
 
-  bf16x8 ra[3][2], rb[3][2];
+  V8 ra[NP][2], rb[NP][2];
   auto load_a = [&](int kA) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -149,7 +263,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
       int64_t row = m0 + (v >> 2);
       row = row < g.nrows ? row : 0;          // rows past the end read row 0; their output rows are never stored
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ra[p][j] = *reinterpret_cast<const bf16x8*>(g.Wh + p * g.w_stride + row * Mp + kA + kq);
+      for (int p = 0; p < NP; ++p) ra[p][j] = *reinterpret_cast<const V8*>(g.Wh + p * g.w_stride + row * Mp + kA + kq);
     }
   };
   auto load_b = [&](int kA, int rep) {
@@ -158,65 +272,56 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
       const int v = tid + 256 * j, row = v >> 2, kq = (v & 3) * 8;
       const int col = (n0 + row < Mp) ? n0 + row : 0;     // likewise: columns >= Mp are never stored
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        rb[p][j] = *reinterpret_cast<const bf16x8*>(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + kq);
+      for (int p = 0; p < NP; ++p)
+        rb[p][j] = *reinterpret_cast<const V8*>(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + kq);
     }
   };
   auto store_a = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int v = tid + 256 * j, off = bf16x6_off(v >> 2, (v & 3) * 8);
+      const int v = tid + 256 * j, off = split_off(v >> 2, (v & 3) * 8);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(As + p * CF::PIECE + off) = ra[p][j];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<V8*>(As + p * CF::PIECE + off) = ra[p][j];
     }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int v = tid + 256 * j, off = bf16x6_off(v >> 2, (v & 3) * 8);
+      const int v = tid + 256 * j, off = split_off(v >> 2, (v & 3) * 8);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(Bs + (buf * 3 + p) * CF::PIECE + off) = rb[p][j];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<V8*>(Bs + (buf * NP + p) * CF::PIECE + off) = rb[p][j];
     }
   };
-  // one staged chunk: P = A B^T through the six cross products (small terms first), then acc += diag(scale) P.
+  // one staged chunk: P = A B^T through the cross products (small terms first), then acc += diag(scale) P.
   // The A fragments of a chunk serve all K topic reps, so they are read from LDS once (rep 0) and stay in registers; the
-  // B fragments are read one 16-column group at a time.  LDS reads per chunk: 12 fragments instead of 24.
-  bf16x8 fa[4][3];
-  const int frag = lr * 32 + ((lg ^ bf16x6_swz(lr)) << 3);      // this lane's fragment offset inside a 16-row group
+  // B fragments are read one 16-column group at a time.
+  V8 fa[4][NP];
+  const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);      // this lane's fragment offset inside a 16-row group
   auto read_a = [&]() {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[a][p] = *reinterpret_cast<const bf16x8*>(As + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
+      for (int p = 0; p < NP; ++p) fa[a][p] = *reinterpret_cast<const V8*>(As + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
   };
-  auto read_b = [&](bf16x8 (&fb)[3], int b, int buf) {
+  auto read_b = [&](V8 (&fb)[NP], int b, int buf) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(Bs + (buf * 3 + p) * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+    for (int p = 0; p < NP; ++p) fb[p] = *reinterpret_cast<const V8*>(Bs + (buf * NP + p) * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
   };
-  auto compute = [&](const float* sc_row /* scaleS + rep*128, or nullptr for scale 1 */, int buf) {
+  auto compute = [&](const float* sc_row /* scaleS + rep*128 */, int buf) {
     f32x4 s4[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-      s4[a] = sc_row ? *reinterpret_cast<const f32x4*>(sc_row + wr * 64 + a * 16 + lg * 4) : f32x4{1, 1, 1, 1};   // rows 4*lg + r
-    bf16x8 fbq[2][3];                      // the next column group's fragments are read while this one multiplies
+    for (int a = 0; a < 4; ++a) s4[a] = *reinterpret_cast<const f32x4*>(sc_row + wr * 64 + a * 16 + lg * 4);   // rows 4*lg + r
+    V8 fbq[2][NP];                         // the next column group's fragments are read while this one multiplies
     read_b(fbq[0], 0, buf);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      bf16x8 (&fb)[3] = fbq[b & 1];
+      V8 (&fb)[NP] = fbq[b & 1];
       if (b + 1 < 4) read_b(fbq[(b + 1) & 1], b + 1, buf);
       f32x4 P[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[2], f32x4{0, 0, 0, 0}, 0, 0, 0);
+      for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][1], fb[1], P[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][2], fb[0], P[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[1], P[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][1], fb[0], P[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) P[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[0], P[a], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) P[a] = SP::mma(fa[a][SP::pa(t)], fb[SP::pb(t)], t == 0 ? f32x4{0, 0, 0, 0} : P[a]);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -247,7 +352,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
     // were measured starving, ~1600 cycles for six, while its SIMD's other wave streams MFMAs).  One wave-instruction moves a
     // 16-row block of one piece image, 1 KB: lane l lands at block + 16 l = row l>>2, physical quad l&3, so its SOURCE is
     // logical quad (l&3) ^ swz(row) - the image swizzle goes on the global address (cdna_hip_programming.md 5.4 rule 21).
-    const int drow = lane >> 2, dq = ((lane & 3) ^ bf16x6_swz(drow)) * 8;
+    const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -259,9 +364,9 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
         const int rbk = wave_u + 4 * i, row = rbk * 16 + drow;
         const int col = (n0 + row < Mp) ? n0 + row : 0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
           __builtin_amdgcn_global_load_lds((gptr_t)(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + q) * Mp + col) * 32 + dq),
-                                           (lptr_t)(Bs + ((c & 1) * 3 + p) * CF::PIECE + rbk * 512), 16, 0, 0);
+                                           (lptr_t)(Bs + ((c & 1) * NP + p) * CF::PIECE + rbk * 512), 16, 0, 0);
       }
     };
     auto dma_a = [&](int q) {             // this group's A image for reduction block q
@@ -272,7 +377,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
         int64_t row = m0 + rbk * 16 + drow;
         row = row < g.nrows ? row : 0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
           __builtin_amdgcn_global_load_lds((gptr_t)(g.Wh + p * g.w_stride + row * Mp + q * CF::BK + dq),
                                            (lptr_t)(As + p * CF::PIECE + rbk * 512), 16, 0, 0);
       }
@@ -301,42 +406,45 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
       if ((ph & 1) == gp) {
         mult(t);
         phase_barrier();
-        } else if (gp == 0) {
+      } else if (gp == 0) {
         const int c = t + 2;
         if (c < nchunks && c % K == 0) dma_a(c / K);
-          phase_barrier();
-        } else {
+        phase_barrier();
+      } else {
         const int c = t + 1;
         dma_b(c);
         if (c < nchunks && c % K == 0) dma_a(c / K);
-          phase_barrier();
-        }
+        phase_barrier();
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  // rank-K epilogue term locbar^T U as extra chunk(s), split on the fly
-  for (int x = 0; x * CF::BK < K; ++x) {
-    __syncthreads();
-    for (int e = tid; e < GDRF_TILE * CF::BK; e += 256) {
-      const int kk = e / GDRF_TILE, row = e - kk * GDRF_TILE, k = x * CF::BK + kk;
-      const float va = (k < K && m0 + row < g.nrows) ? g.locbar[(int64_t)k * g.ldk + m0 + row] : 0.0f;
-      const float vb = (k < K && n0 + row < g.M) ? g.U[(int64_t)k * g.M + n0 + row] : 0.0f;
-      __bf16 h, m, l;
-      split3(va, h, m, l);
-      const int o = bf16x6_off(row, kk);
-      As[o] = h; As[CF::PIECE + o] = m; As[2 * CF::PIECE + o] = l;
-      split3(vb, h, m, l);
-      Bs[o] = h; Bs[CF::PIECE + o] = m; Bs[2 * CF::PIECE + o] = l;
+  // rank-K epilogue term locbar^T U on the native f32 matrix instruction (exact f32, no split, no range question): lane
+  // (lr, lg) supplies A[row lr][k = lg] and B[k = lg][col lr] of v_mfma_f32_16x16x4_f32, whose C/D layout is the accumulators'
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + lg;
+    float av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t row = m0 + wr * 64 + a * 16 + lr;
+      av[a] = (k < K && row < g.nrows) ? g.locbar[(int64_t)k * g.ldk + row] : 0.0f;
     }
-    __syncthreads();
-    read_a();
-    compute(nullptr, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = n0 + wc * 64 + b * 16 + lr;
+      bv[b] = (k < K && col < g.M) ? g.U[(int64_t)k * g.M + col] : 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
   }
   // Wbar = acc - 2 asum W.  The MFMA accumulator layout (a lane owns one column of four rows) would make this 64 scalar
   // loads of W and 64 scalar stores per lane in a dependent sequence - measured ~300k cycles per workgroup, a third of its
   // lifetime.  Instead each wave transposes its 64 x 64 quadrant through a private LDS tile, 32 rows at a time, and moves whole
   // 256-byte row segments: 16 float4 loads and 16 float4 stores per lane.
   __syncthreads();                                           // every wave is done with the operand images
+  float wmax = 0.0f;
   {
     constexpr int TS = 68;                                   // tile row stride in floats (272 B: 16-byte aligned, bank-shifted)
     float* tile = reinterpret_cast<float*>(smem) + (size_t)((NG == 2 ? gp * 4 : 0) + wave) * (32 * TS);
@@ -360,43 +468,52 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_bf16x6_kernel(BwdWbarBf1
           const f32x4 w = *reinterpret_cast<const f32x4*>(g.W + m * Mp + n);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = t[e] - as2 * w[e];
+          for (int e = 0; e < 4; ++e) { o[e] = t[e] - as2 * w[e]; wmax = fmaxf(wmax, fabsf(o[e])); }
           *reinterpret_cast<f32x4*>(g.Wbar + m * Mp + n) = o;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the tile is overwritten with the other half
     }
   }
+  if (g.wbar_max) {                                          // order-independent: the maximum of non-negative floats as integers
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0 && wmax > 0.0f) atomicMax(g.wbar_max, __float_as_uint(wmax));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // tt[k][n] = || S_k^T w_n ||^2 on the same emulation: T_k = W S_k lives only in the accumulators; a row tile and topic walk
 // the column tiles (triangular k range i >= j), as gemm_nt<FwdTProb> does.
-struct FwdTBf16Args {
-  const __bf16* Wh; int64_t w_stride; int64_t nrows; int Mp, K;
+template <class SP> struct FwdTSplitArgs {
+  const typename SP::E* Wh; int64_t w_stride; int64_t nrows; int Mp, K;
   int KG; int rt8;                            // topics per group (see the block map), ceil(row-tile pairs / 8)
-  const __bf16* STh; int64_t piece_stride;    // STh[p][k][i / 32][j][i % 32] = pieces of S_k[i][j] (k-blocked)
+  const typename SP::E* STh; int64_t piece_stride;    // STh[p][k][i / 32][j][i % 32] = pieces of S_k[i][j] (k-blocked)
   float* tt; int64_t ldt;
+  const float* sc;
 };
 
-// ------------------------------------------------------------------------------------------------------------------
-// tt in the two-group LDS-DMA structure of bwd_wbar_bf16x6_kernel<2>: a 512-thread workgroup holds two adjacent row tiles of
+// tt in the two-group LDS-DMA structure of bwd_wbar_split_kernel<2>: a 512-thread workgroup holds two adjacent row tiles of
 // one topic, one per wave group; both walk the same (column tile, reduction chunk) sequence, so the S_k^T chunk is staged once
 // (by group 1) into a double-buffered image both read, and every group double-buffers its own W chunk.  Chunk c is multiplied
 // by group 0 in phase 2c and by group 1 in phase 2c+1; DMAs are issued in a group's idle phase two chunks ahead (group 0) / one
 // chunk ahead (group 1), land during its next multiply phase and are retired by the vmcnt(0) that ends it.
 // Grid: 8 * K * rt8 with rt8 = ceil(row-tile pairs / 8).  Block map: XCD = blockIdx & 7 owns the pairs r * 8 + xcd; topics go
 // in groups of KG, group-major (every XCD first runs all its pairs for topics [0, KG), then [KG, 2 KG), ...) so that only KG
-// topics' S^T pieces (~1 MB each at M = 512) are live in its 4 MB L2 at a time; the KG workgroups of one pair are adjacent.
-__global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g) {
-  using CF = Bf16x6Cfg;
+// topics' S^T pieces are live in its 4 MB L2 at a time; the KG workgroups of one pair are adjacent.
+template <class SP>
+__global__ __launch_bounds__(512, 2) void fwd_t_split_2g_kernel(FwdTSplitArgs<SP> g) {
+  using CF = SplitCfg<SP>;
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  constexpr int NP = SP::NP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int IMG = 3 * CF::PIECE;                          // halfwords per operand image
+  constexpr int IMG = CF::IMG;
   const int gp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
-  __bf16* As = reinterpret_cast<__bf16*>(smem) + gp * 2 * IMG;      // [2 buffers][3][128][32] of this group
-  __bf16* Bs = reinterpret_cast<__bf16*>(smem) + 4 * IMG;           // [2 buffers][3][128][32] shared
+  E* As = reinterpret_cast<E*>(smem) + gp * 2 * IMG;      // [2 buffers][NP][128][32] of this group
+  E* Bs = reinterpret_cast<E*>(smem) + 4 * IMG;           // [2 buffers][NP][128][32] shared
   const int Mp = g.Mp;
   const int nct = (Mp + GDRF_TILE - 1) / GDRF_TILE;
   const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
@@ -417,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
       c -= len;
     }
   };
-  const int drow = lane >> 2, dq = ((lane & 3) ^ bf16x6_swz(drow)) * 8;
+  const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -430,9 +547,9 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
       const int rbk = wave_u + 4 * i, row = rbk * 16 + drow;
       const int col = (ct * GDRF_TILE + row < Mp) ? ct * GDRF_TILE + row : 0;      // columns >= Mp are skipped when the tile is folded
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
         __builtin_amdgcn_global_load_lds((gptr_t)(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + dq),
-                                         (lptr_t)(Bs + ((c & 1) * 3 + p) * CF::PIECE + rbk * 512), 16, 0, 0);
+                                         (lptr_t)(Bs + ((c & 1) * NP + p) * CF::PIECE + rbk * 512), 16, 0, 0);
     }
   };
   auto dma_a = [&](int c) {
@@ -445,9 +562,9 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
       int64_t row = m0 + rbk * 16 + drow;
       row = row < g.nrows ? row : 0;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
         __builtin_amdgcn_global_load_lds((gptr_t)(g.Wh + p * g.w_stride + row * Mp + kA + dq),
-                                         (lptr_t)(As + ((c & 1) * 3 + p) * CF::PIECE + rbk * 512), 16, 0, 0);
+                                         (lptr_t)(As + ((c & 1) * NP + p) * CF::PIECE + rbk * 512), 16, 0, 0);
     }
   };
   float rs[4][4];
@@ -456,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) rs[a][r] = 0;
   f32x4 acc[4][4];
-  const int frag = lr * 32 + ((lg ^ bf16x6_swz(lr)) << 3);
+  const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);
   auto mult = [&](int c) {
     int ct, kA; bool first, last;
     decode(c, ct, kA, first, last);
@@ -466,35 +583,27 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
     }
-    const __bf16* Ab = As + (c & 1) * IMG;
-    const __bf16* Bb = Bs + (c & 1) * IMG;
-    bf16x8 fb[3][4];
+    const E* Ab = As + (c & 1) * IMG;
+    const E* Bb = Bs + (c & 1) * IMG;
+    V8 fb[NP][4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const bf16x8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
-    bf16x8 faq[2][3];
+      for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+    V8 faq[2][NP];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) faq[0][p] = *reinterpret_cast<const bf16x8*>(Ab + p * CF::PIECE + (wr * 64) * 32 + frag);
+    for (int p = 0; p < NP; ++p) faq[0][p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64) * 32 + frag);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bf16x8 (&fa)[3] = faq[a & 1];
+      V8 (&fa)[NP] = faq[a & 1];
       if (a + 1 < 4) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) faq[(a + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(Ab + p * CF::PIECE + (wr * 64 + (a + 1) * 16) * 32 + frag);
+        for (int p = 0; p < NP; ++p) faq[(a + 1) & 1][p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + (a + 1) * 16) * 32 + frag);
       }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2][b], acc[a][b], 0, 0, 0);
+      for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) acc[a][b] = SP::mma(fa[SP::pa(t)], fb[SP::pb(t)][b], acc[a][b]);
     }
     if (last) {                                                 // fold the finished column tile into the row sums
 #pragma unroll
@@ -529,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
     phase_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // row sums: 16-lane groups, then the two waves of a group that share the rows, through LDS
+  // row sums: 16-lane groups, then the two waves of a group that share the rows, through LDS; the block scales come off here
   float* rsum = reinterpret_cast<float*>(smem) + gp * GDRF_TILE;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -552,16 +661,18 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
   __syncthreads();
   if (tid < GDRF_TILE) {
     const int64_t m = m0 + tid;
-    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = rsum[tid];
+    const SplitLay SL{g.K};
+    const float un = g.sc[SL.w() + 1] * g.sc[SL.st(bz) + 1];
+    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = rsum[tid] * (un * un);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // TN form (reduction over observations):  C[i][j] = sum_n A[n][i] * s[n] * B[n][j]  on the same emulation; replaces
 // gemm_tn_kernel<float> for A_k = W^T diag(vbar_k) W (sym) and GT = W^T Wbar.  A comes pre-split (Wh), B is f32 and is
-// scaled by s[n] and split when it is staged (the scale runs along the reduction index, so it cannot be pulled out of the
-// product).  Both operands are staged as they lie in memory (n-major rows) and the MFMA fragments (8 consecutive n per lane)
-// are gathered with the transposing LDS read ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
+// scaled by s[n] (and its block scale) and split when it is staged (the scale runs along the reduction index, so it cannot be
+// pulled out of the product).  Both operands are staged as they lie in memory (n-major rows) and the MFMA fragments (8
+// consecutive n per lane) are gathered with the transposing LDS read ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
 //
 // LDS piece image of a 32 (n) x 128 (column) chunk: row-major (256-byte rows, so an LDS-DMA instruction fills 4 whole rows
 // from the row-major pieces), with the 8-byte column quad c4 XOR-swizzled by the row:
@@ -569,27 +680,43 @@ __global__ __launch_bounds__(512, 2) void fwd_t_bf16x6_2g_kernel(FwdTBf16Args g)
 // A transposing fragment read of a half-wave touches rows k = 8 lg + 4 h + q (lg in {0,1} or {2,3}, q = 0..3) x quads base + p,
 // p = 0..3: the eight (lg & 1, q) codes send the eight rows to eight different 32-byte groups of the 256-byte bank window -
 // conflict-free.  The pre-split A operand is staged by DMA (double-buffered, no registers, no LDS stores); the B operand, which
-// must be scaled and split, goes through registers and 6 ds_write_b128 per thread.
-struct TNBf16Args {
-  const __bf16* Ah; int64_t a_stride; int64_t lda;     // pieces [p][n][lda]
+// must be scaled and split, goes through registers and NP ds_write_b128 per row pair.
+template <class SP> struct TNSplitArgs {
+  const typename SP::E* Ah; int64_t a_stride; int64_t lda;     // pieces [p][n][lda]
   const float* B; int64_t ldb;                         // [n][ldb]
   const float* scale; int64_t scale_bs;                // optional per-row scale, batch stride; nullptr = 1
   int64_t nrows, rows_per_split;                       // rows_per_split multiple of 32
   int ncols, sym;
   float* slab;                                         // [nsplit][nbatch][ncols][ncols]
   int nbatch, nsplit;
+  const float* sc; int sidx_a;                         // block scales: pair index of the A pieces' scale,
+  int sidx_b, sidx_b_stride;                           //   of the B operand's (per batch: sidx_b + stride * b),
+  int b_times_a_scale;                                 //   1: the raw B data is unscaled W, it also takes A's scale (A_k)
 };
 
 __device__ __forceinline__ int tnb_code(int k) { return (((k >> 3) & 1) << 2) | (k & 3); }
 __device__ __forceinline__ int tnb_seg(int k, int c4) { return k * 32 + (c4 ^ (tnb_code(k) << 2)); }
 
+__device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ f16x4 tr_read(const _Float16* p) {
+  typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));       // the builtin's own vector type; same bits
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)p));
+}
+
 // 192 registers at most (amdgpu_num_vgpr counts half of the unified file): one wave of this kernel then shares a SIMD's 512 with two
 // 160-register waves of bwd_knm on the other stream (api.hip), which is how G^T runs inside that kernel's stalls
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void gemm_tn_bf16x6_kernel(TNBf16Args g) {
+template <class SP>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void gemm_tn_split_kernel(TNSplitArgs<SP> g) {
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  using V4 = typename SP::V4;
+  constexpr int NP = SP::NP;
   constexpr int PIECE = 32 * 128;             // halfwords per piece image (8 KB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem);           // [2 buffers][3][32][128]
-  __bf16* Bs = As + 6 * PIECE;                             // [3][32][128]
+  E* As = reinterpret_cast<E*>(smem);         // [2 buffers][NP][32][128]
+  E* Bs = As + 2 * NP * PIECE;                // [NP][32][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   const int nt = (g.ncols + GDRF_TILE - 1) / GDRF_TILE;
@@ -617,6 +744,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   const int64_t r0 = (int64_t)sp * g.rows_per_split;
   int64_t r1 = r0 + g.rows_per_split; if (r1 > g.nrows) r1 = g.nrows;
   const float* sc = g.scale ? g.scale + (int64_t)b * g.scale_bs : nullptr;
+  const int sb = g.sidx_b + g.sidx_b_stride * b;
+  const float bscale = g.sc[sb] * (g.b_times_a_scale ? g.sc[g.sidx_a] : 1.0f);                              // applied to B at the split
+  const float unscale = g.sc[g.sidx_a + 1] * g.sc[sb + 1] * (g.b_times_a_scale ? g.sc[g.sidx_a + 1] : 1.0f);  // taken off the result
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -640,9 +770,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
       n = n < g.nrows ? n : g.nrows - 1;
       const int col = (i0 + c8 * 8 < g.ncols) ? i0 + c8 * 8 : 0;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
         __builtin_amdgcn_global_load_lds((gptr_t)(g.Ah + p * g.a_stride + n * g.lda + col),
-                                         (lptr_t)(As + ((c & 1) * 3 + p) * PIECE + blk * 512), 16, 0, 0);
+                                         (lptr_t)(As + ((c & 1) * NP + p) * PIECE + blk * 512), 16, 0, 0);
     }
   };
   // B: 8 columns of a row per vector pair (q = tid&3 -> row 4*(khi + 4 i) + q, c8 = (tid>>2)&15, khi = tid>>6), 2 rows per thread:
@@ -670,63 +800,57 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   int xa[4], xb[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) { xa[t] = fbase + (((4 * wr + t) ^ fcode) << 2); xb[t] = fbase + (((4 * wc + t) ^ fcode) << 2); }
-  auto frag = [&](const __bf16* img, int seg) -> bf16x8 {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + seg * 4));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + (seg + 128) * 4));
+  auto frag = [&](const E* img, int seg) -> V8 {
+    const V4 lo = tr_read(img + seg * 4);
+    const V4 hi = tr_read(img + (seg + 128) * 4);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
   // symmetric problem, diagonal tile: the quadrant above the diagonal (rows 0-63 x columns 64-127) is the mirror image of the one
   // below it and reduce_slabs_kernel takes it from there.  Its wave skips fragment reads and MFMAs - a quarter of the tile's LDS
-  // read traffic, which is what bounds this kernel - and only stages.
+  // read traffic - and only stages.
   const bool idle = g.sym && ti == tj && __builtin_amdgcn_readfirstlane(wave) == 1;
   if (nch > 0) { dma_a(0); load_b(0); }
   for (int c = 0; c < nch; ++c) {
     // scale and split the prefetched B vectors BEFORE the barrier: the conversion then overlaps the other waves' MFMAs
     // instead of sitting in the barrier-to-barrier staging section
-    bf16x8 hb[2], mb[2], lb[2];
+    V8 pb[2][NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      const float s = rs[i] * bscale;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        __bf16 x1, x2, x3;
-        split3(rb[2 * i + (e >> 2)][e & 3] * rs[i], x1, x2, x3);
-        hb[i][e] = x1; mb[i][e] = x2; lb[i][e] = x3;
+        E p[NP];
+        SP::split(rb[2 * i + (e >> 2)][e & 3] * s, p);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) pb[i][q][e] = p[q];
       }
+    }
     __syncthreads();                       // (its vmcnt(0) also retires this wave's DMA of chunk c, issued one iteration ago)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int so = tnb_seg(4 * (b_kh + 4 * i) + sq, 2 * b_c8) * 4;
-      *reinterpret_cast<bf16x8*>(Bs + so) = hb[i];
-      *reinterpret_cast<bf16x8*>(Bs + PIECE + so) = mb[i];
-      *reinterpret_cast<bf16x8*>(Bs + 2 * PIECE + so) = lb[i];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<V8*>(Bs + q * PIECE + so) = pb[i][q];
     }
     __syncthreads();
     if (c + 1 < nch) { dma_a(c + 1); load_b(c + 1); }          // A buffer (c+1)&1 was last read in iteration c-1
     if (idle) continue;                                        // staged and synchronised with the others; nothing of its own to multiply
-    const __bf16* Ab = As + (c & 1) * 3 * PIECE;
-    bf16x8 fb[3][4];
+    const E* Ab = As + (c & 1) * NP * PIECE;
+    V8 fb[NP][4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int t = 0; t < 4; ++t) fb[p][t] = frag(Bs + p * PIECE, xb[t]);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bf16x8 fa[3];
+      V8 fa[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[p] = frag(Ab + p * PIECE, xa[a]);
+      for (int p = 0; p < NP; ++p) fa[p] = frag(Ab + p * PIECE, xa[a]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2][t], acc[a][t], 0, 0, 0);
+      for (int t2 = 0; t2 < SP::NPROD; ++t2)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1][t], acc[a][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0][t], acc[a][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1][t], acc[a][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0][t], acc[a][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0][t], acc[a][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[a][t] = SP::mma(fa[SP::pa(t2)], fb[SP::pb(t2)][t], acc[a][t]);
     }
   }
   if (idle) return;
@@ -739,7 +863,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * 64 + a * 16 + lg * 4 + r;
         const int j = j0 + wc * 64 + c * 16 + lr;
-        if (i < g.ncols && j < g.ncols) out[(int64_t)i * g.ncols + j] = acc[a][c][r];
+        if (i < g.ncols && j < g.ncols) out[(int64_t)i * g.ncols + j] = acc[a][c][r] * unscale;
       }
 }
 

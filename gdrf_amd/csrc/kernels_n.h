@@ -8,6 +8,7 @@
 #include "common.h"
 #include "gemm_nt.h"
 #include "kernels_mm.h"
+#include "gemm_split.h"
 
 
 namespace gdrf {
@@ -168,7 +169,8 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
   static constexpr int DEPTH = 1;
   const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
-  __bf16* Wh = nullptr; int64_t wh_stride = 0;        // optional: the 3 bf16 pieces of W (gemm_bf16x6.h), written by the same epilogue
+  void* Wh = nullptr; int64_t wh_stride = 0;          // optional: the 16-bit pieces of W (gemm_split.h), written by the same epilogue
+  int wh_mode = 0; const float* wh_scale = nullptr;   // 1: three bf16 pieces; 2: two fp16 pieces of W * wh_scale[0]
   struct ACtx { const T* p[NTCfg<T>::VPT]; };
   struct ECtx { T rs[4][4]; int ct; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
@@ -216,6 +218,7 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
         constexpr int TS_ = 36;                               // tile row stride in floats (144 B)
         float* tile = reinterpret_cast<float*>(nt_smem) + (threadIdx.x >> 6) * (32 * TS_);
         const int lr = lane & 15, lg = lane >> 4;
+        const float wsc = wh_scale ? wh_scale[0] : 1.0f;
         __syncthreads();                                      // every wave is done with the operand images of the last chunk
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -232,21 +235,24 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
             const int64_t m = m0 + wr * 64 + h * 32 + rr;
             const int n = n0 + wc * (NTCfg<T>::CW / 2) + cv;
             typedef float f4 __attribute__((ext_vector_type(4)));
-            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
             const f4 t = *reinterpret_cast<const f4*>(tile + rr * TS_ + cv);
             if (m < nrows && n < Mp) {                        // Mp is a multiple of 32: a vector never straddles the edge
               *reinterpret_cast<f4*>(W + m * Mp + n) = t;
-              b4 ph, pm, pl;
+              auto put = [&](auto sp) {
+                using SP = decltype(sp);
+                typename SP::V4 pv[SP::NP];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const __bf16 x1 = (__bf16)t[e];
-                const float r1 = t[e] - (float)x1;
-                const __bf16 x2 = (__bf16)r1;
-                ph[e] = x1; pm[e] = x2; pl[e] = (__bf16)(r1 - (float)x2);
-              }
-              *reinterpret_cast<b4*>(Wh + m * Mp + n) = ph;
-              *reinterpret_cast<b4*>(Wh + wh_stride + m * Mp + n) = pm;
-              *reinterpret_cast<b4*>(Wh + 2 * wh_stride + m * Mp + n) = pl;
+                for (int e = 0; e < 4; ++e) {
+                  typename SP::E pc[SP::NP];
+                  SP::split(t[e] * wsc, pc);
+#pragma unroll
+                  for (int q = 0; q < SP::NP; ++q) pv[q][e] = pc[q];
+                }
+#pragma unroll
+                for (int q = 0; q < SP::NP; ++q)
+                  *reinterpret_cast<typename SP::V4*>(reinterpret_cast<typename SP::E*>(Wh) + q * wh_stride + m * Mp + n) = pv[q];
+              };
+              if (wh_mode == 2) put(SplitF16{}); else put(SplitBf16{});
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -786,11 +792,14 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
 // =====================================================================================
 // elbo_rows: per observation: variance, reparameterised draw, softmax link, Multinomial
 // log-likelihood, both Normal site terms, and the row-local part of the backward.
-// One thread per row, K <= GDRF_KMAX kept in registers.
+// One thread per row.  The workgroup's RB rows of counts (RB * V contiguous int32) are staged into LDS with whole-line
+// 16-byte loads and each thread then walks its own row there (row stride V + 1: conflict-free), instead of every lane
+// striding through HBM V * 4 bytes apart.  KREG: K <= GDRF_KMAX, the per-topic values of a row live in registers; otherwise
+// they are re-read from the (K, n) arrays (coalesced over the rows) and the softmax pull-back goes through LDS - any K.
 // =====================================================================================
 #define GDRF_KMAX 32
 
-template <typename T>
+template <typename T, bool KREG>
 __global__ __launch_bounds__(128) void elbo_rows_kernel(
     int64_t nrows, int K, int V, const Hyper* __restrict__ h,
     const T* __restrict__ qpart, int nqpart, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps,
@@ -801,11 +810,13 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     double* __restrict__ dpart /*[grid][4]*/, T* __restrict__ phibar_part /*[grid][K*V]*/) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int RB = blockDim.x;
+  constexpr int KR = KREG ? GDRF_KMAX : 1;
   double* scratch = reinterpret_cast<double*>(smem);    // [16]
   T* phiS = reinterpret_cast<T*>(smem + 128);           // [K*V]
   T* accS = phiS + K * V;                               // [K*V] phibar accumulator (owner-thread only)
   T* thS = accS + K * V;                                // [RB][K+1]
   T* pbS = thS + RB * (K + 1);                          // [RB][V+1]
+  T* tbS = pbS + RB * (V + 1);                          // [RB][K+1], !KREG only
   for (int e = threadIdx.x; e < K * V; e += RB) { phiS[e] = phi[e]; accS[e] = 0; }
   __syncthreads();
   const T var = (T)h->var, eta = (T)h->noise;
@@ -817,7 +828,24 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     const bool ok = n < nrows;
     T* th = thS + threadIdx.x * (K + 1);
     T* pb = pbS + threadIdx.x * (V + 1);
-    T v[GDRF_KMAX], mu[GDRF_KMAX], ep[GDRF_KMAX];
+    T* tbl = tbS + threadIdx.x * (K + 1);
+    {   // counts of this block's rows -> pbS (as T): element e of the contiguous RB x V block is row e / V, taxon e % V
+      const int64_t e0 = blk * RB * (int64_t)V;
+      int64_t cnt = (nrows - blk * RB < RB ? nrows - blk * RB : (int64_t)RB) * V;
+      const int32_t* src = ws + e0;
+      const int head = (int)((4 - (e0 & 3)) & 3);         // elements in front of the first 16-byte aligned one
+      for (int64_t e = threadIdx.x; e < head && e < cnt; e += RB) pbS[(e / V) * (V + 1) + e % V] = (T)src[e];
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const int64_t nvec = cnt > head ? (cnt - head) >> 2 : 0;
+      for (int64_t q = threadIdx.x; q < nvec; q += RB) {
+        const i32x4 w4 = *reinterpret_cast<const i32x4*>(src + head + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int64_t e = head + 4 * q + j; pbS[(e / V) * (V + 1) + e % V] = (T)w4[j]; }
+      }
+      for (int64_t e = head + 4 * nvec + threadIdx.x; e < cnt; e += RB) pbS[(e / V) * (V + 1) + e % V] = (T)src[e];
+    }
+    __syncthreads();
+    T v[KR], mu[KR], ep[KR];
     T a = 0, vd = 0;
     if (ok) {
       T qn = 0;
@@ -825,35 +853,42 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
       qout[n] = qn;
       a = (var - qn > T(0)) ? T(1) : T(0);
       const T v0 = a * (var - qn);
+      auto topic = [&](int k, T& vk, T& ek, T& mk) {
+        ek = eps[(int64_t)k * lde + n];
+        vk = v0 + tt[(int64_t)k * ldk + n];
+        mk = loc[(int64_t)k * ldk + n] + vk * ek;
+        if (mean) mk += mean[(int64_t)k * mean_sk + n * mean_sn];   // f_loc + mean_function(xs): the site terms only see mu - f_loc
+      };
       T mx = -3.0e38f;
+      if constexpr (KREG) {
 #pragma unroll
-      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) {
-        ep[k] = eps[(int64_t)k * lde + n];
-        v[k] = v0 + tt[(int64_t)k * ldk + n];
-        mu[k] = loc[(int64_t)k * ldk + n] + v[k] * ep[k];
-        if (mean) mu[k] += mean[(int64_t)k * mean_sk + n * mean_sn];   // f_loc + mean_function(xs): the site terms only see mu - f_loc
-        mx = fmax(mx, mu[k]);
+        for (int k = 0; k < KR; ++k) if (k < K) { topic(k, v[k], ep[k], mu[k]); mx = fmax(mx, mu[k]); }
+      } else {
+        for (int k = 0; k < K; ++k) { T vk, ek, mk; topic(k, vk, ek, mk); th[k] = mk; mx = fmax(mx, mk); }
       }
       T se = 0;
+      if constexpr (KREG) {
 #pragma unroll
-      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) { const T e = t_exp<T>(mu[k] - mx); th[k] = e; se += e; }
+        for (int k = 0; k < KR; ++k) if (k < K) { const T e = t_exp<T>(mu[k] - mx); th[k] = e; se += e; }
+      } else {
+        for (int k = 0; k < K; ++k) { const T e = t_exp<T>(th[k] - mx); th[k] = e; se += e; }
+      }
       const T ise = T(1) / se;
       for (int k = 0; k < K; ++k) th[k] *= ise;
-      // pass 1: p_v = sum_k theta_k phi_kv
+      // pass 1: p_v = sum_k theta_k phi_kv ; pass 2: log-likelihood and pbar = w * mask / p
       T ps = 0;
       for (int vv = 0; vv < V; ++vv) {
         T p = 0;
         for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
-        pb[vv] = p; ps += p;
+        ps += p;
       }
-      // pass 2: log-likelihood and pbar = w * mask / p
       const T ips = T(1) / ps;
       T llw = 0;
-      const int32_t* wrow = ws + n * V;
       for (int vv = 0; vv < V; ++vv) {
-        const T p = pb[vv];
+        T p = 0;
+        for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
         const T ph = p * ips;
-        const T wv = (T)wrow[vv];
+        const T wv = pb[vv];
         const bool inr = (ph > feps) && (ph < T(1) - feps);
         const T phc = fmin(fmax(ph, feps), T(1) - feps);
         llw += wv * t_log<T>(phc);
@@ -861,27 +896,40 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
       }
       s_llw += (double)llw;
       // thetabar_k = sum_v phi_kv pbar_v ; softmax Jacobian
-      T tb[GDRF_KMAX];
+      T tb[KR];
       T dot = 0;
+      if constexpr (KREG) {
 #pragma unroll
-      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) {
-        T s = 0;
-        for (int vv = 0; vv < V; ++vv) s += phiS[k * V + vv] * pb[vv];
-        tb[k] = s; dot += th[k] * s;
+        for (int k = 0; k < KR; ++k) if (k < K) {
+          T s = 0;
+          for (int vv = 0; vv < V; ++vv) s += phiS[k * V + vv] * pb[vv];
+          tb[k] = s; dot += th[k] * s;
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          T s = 0;
+          for (int vv = 0; vv < V; ++vv) s += phiS[k * V + vv] * pb[vv];
+          tbl[k] = s; dot += th[k] * s;
+        }
       }
       T site = 0, ng = 0, vsum = 0;
-#pragma unroll
-      for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) {
-        const T mub = th[k] * (tb[k] - dot);
-        const T s = v[k] + eta, r = v[k] / s, e2 = ep[k] * ep[k];
-        site += -t_log<T>(s) + t_log<T>(v[k]) - T(0.5) * e2 * r * r + T(0.5) * e2;
-        const T dcdv = -T(1) / s + T(1) / v[k] - e2 * r * eta / (s * s);
+      auto finish_topic = [&](int k, T vk, T ek, T mk, T tbk) {
+        const T mub = th[k] * (tbk - dot);
+        const T s = vk + eta, r = vk / s, e2 = ek * ek;
+        site += -t_log<T>(s) + t_log<T>(vk) - T(0.5) * e2 * r * r + T(0.5) * e2;
+        const T dcdv = -T(1) / s + T(1) / vk - e2 * r * eta / (s * s);
         ng += -T(1) / s + e2 * r * r / s;
-        const T vb = mub * ep[k] + dcdv;
+        const T vb = mub * ek + dcdv;
         vbar[(int64_t)k * ldk + n] = vb;
         locbar[(int64_t)k * ldk + n] = mub;
-        if (mu_out) mu_out[(int64_t)k * ldk + n] = mu[k];
+        if (mu_out) mu_out[(int64_t)k * ldk + n] = mk;
         vsum += vb;
+      };
+      if constexpr (KREG) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) if (k < K) finish_topic(k, v[k], ep[k], mu[k], tb[k]);
+      } else {
+        for (int k = 0; k < K; ++k) { T vk, ek, mk; topic(k, vk, ek, mk); finish_topic(k, vk, ek, mk, tbl[k]); }
       }
       vd = a * vsum;
       asum[n] = vd;
@@ -907,6 +955,17 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     dpart[4 * (int64_t)blockIdx.x + 2] = b2; dpart[4 * (int64_t)blockIdx.x + 3] = b3;
   }
   for (int e = threadIdx.x; e < K * V; e += RB) phibar_part[(int64_t)blockIdx.x * K * V + e] = accS[e];
+}
+
+// vmax[k] = bits of max_n |x[k][n]| (floats are ordered like their bit patterns when non-negative); vmax zeroed by the caller
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, int64_t n, int64_t ld, unsigned* __restrict__ vmax) {
+  const int k = blockIdx.y;
+  float m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[(int64_t)k * ld + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(vmax + k, __float_as_uint(m));
 }
 
 // =====================================================================================
@@ -1000,6 +1059,33 @@ __global__ void reduce_dparts_kernel(const double* __restrict__ part, int64_t np
     s = block_sum(s, scratch);
     if (threadIdx.x == 0) out[c] = s;
   }
+}
+// The doubles of red_d travelling in the element type of the flat payload, so that ONE all-reduce carries the whole step
+// (SURVEY.md 8(e)).  double payload: copied.  float payload: d = p0 + p1 + p2 + p3 with 12-bit-mantissa pieces p0..p2 (the
+// remainder p3 keeps 24 bits): sums of <= 8 such pieces of similar magnitude are exact in float, so the reduced value is the
+// f64 sum to ~2^-48 (worst case, ranks whose values differ by > 2^9: the float rounding of the largest piece, 2^-24).
+template <typename T>
+__global__ void payload_pack_kernel(const double* __restrict__ d, int nd, T* __restrict__ tail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nd) return;
+  if constexpr (sizeof(T) == 8) { tail[i] = d[i]; }
+  else {
+    double r = d[i];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const float f = __uint_as_float(__float_as_uint((float)r) & 0xFFFFF000u);
+      tail[p * nd + i] = f;
+      r -= (double)f;
+    }
+    tail[3 * nd + i] = (float)r;
+  }
+}
+template <typename T>
+__global__ void payload_unpack_kernel(const T* __restrict__ tail, int nd, double* __restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nd) return;
+  if constexpr (sizeof(T) == 8) { d[i] = tail[i]; }
+  else d[i] = (((double)tail[3 * nd + i] + (double)tail[2 * nd + i]) + (double)tail[nd + i]) + (double)tail[i];
 }
 // TN slabs: out[b][i][j] = sum_sp slab[sp][b][i][j]; symmetric batches only hold tiles ti >= tj and are mirrored
 template <typename T>
@@ -1157,6 +1243,78 @@ __global__ __launch_bounds__(128) void predict_rows_kernel(const TN* __restrict_
       if (mode == 2) out[n * ldo + v] = (TN)p;
       else { const double w = (double)ws[n * V + v]; s_wlp += w * (double)t_log<T>(p); s_w += w; }
     }
+  }
+  if (mode == 3) {
+    const double a = block_sum(s_wlp, scratch), b = block_sum(s_w, scratch);
+    if (threadIdx.x == 0) { dpart[2 * (int64_t)blockIdx.x] = a; dpart[2 * (int64_t)blockIdx.x + 1] = b; }
+  }
+}
+
+// the same for K > GDRF_KMAX: topics in chunks of GDRF_KMAX (the covariance row is re-evaluated per chunk), softmax over all K
+// in two sweeps (running maximum and sum, then the normalised values); word_probs accumulate in an LDS row per thread
+template <typename T, typename TN>
+__global__ __launch_bounds__(128) void predict_rows_bigk_kernel(const TN* __restrict__ X, int64_t nrows, const T* __restrict__ Z, int M, int D,
+                                                                int kind, const Hyper* __restrict__ h, const T* __restrict__ Cf, int K, int V,
+                                                                const TN* __restrict__ phi, const int32_t* __restrict__ ws, int mode,
+                                                                TN* __restrict__ out, int64_t ldo, double* __restrict__ dpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* scratch = reinterpret_cast<double*>(smem);       // [16]
+  T* Zs = reinterpret_cast<T*>(smem + 128);                // [M*D]
+  T* phiS = Zs + M * D;                                    // [K*V]
+  T* pbS = phiS + K * V;                                   // [blockDim][V+1]
+  for (int e = threadIdx.x; e < M * D; e += blockDim.x) Zs[e] = Z[e];
+  if (mode >= 2) for (int e = threadIdx.x; e < K * V; e += blockDim.x) phiS[e] = (T)phi[e];
+  __syncthreads();
+  const T var = (T)h->var, ils2 = (T)h->inv_ls2;
+  T* pb = pbS + threadIdx.x * (V + 1);
+  double s_wlp = 0, s_w = 0;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < nrows; n += (int64_t)gridDim.x * blockDim.x) {
+    T x[GDRF_DMAX];
+#pragma unroll
+    for (int d = 0; d < GDRF_DMAX; ++d) x[d] = (d < D) ? (T)X[n * D + d] : T(0);
+    T lc[GDRF_KMAX];
+    auto chunk = [&](int k0) {
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) lc[k] = 0;
+      for (int i = 0; i < M; ++i) {
+        T r2 = 0;
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const T t = x[d] - Zs[i * D + d]; r2 += t * t; }
+        const T kv = cov_from_r2<T>(kind, r2 * ils2, var, (T)h->alpha);
+#pragma unroll
+        for (int k = 0; k < GDRF_KMAX; ++k) if (k0 + k < K) lc[k] += kv * Cf[(int64_t)(k0 + k) * M + i];
+      }
+    };
+    T mx = -3.0e38f, se = 0;
+    for (int k0 = 0; k0 < K; k0 += GDRF_KMAX) {
+      chunk(k0);
+      if (mode == 0) {
+#pragma unroll
+        for (int k = 0; k < GDRF_KMAX; ++k) if (k0 + k < K) out[(int64_t)(k0 + k) * ldo + n] = (TN)lc[k];
+        continue;
+      }
+      T cm = mx;
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k0 + k < K) cm = fmax(cm, lc[k]);
+      se *= t_exp<T>(mx - cm);
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k0 + k < K) se += t_exp<T>(lc[k] - cm);
+      mx = cm;
+    }
+    if (mode == 0) continue;
+    const T ise = T(1) / se;
+    if (mode >= 2) for (int v = 0; v < V; ++v) pb[v] = 0;
+    for (int k0 = 0; k0 < K; k0 += GDRF_KMAX) {
+      chunk(k0);
+#pragma unroll
+      for (int k = 0; k < GDRF_KMAX; ++k) if (k0 + k < K) {
+        const T th = t_exp<T>(lc[k] - mx) * ise;
+        if (mode == 1) out[n * ldo + k0 + k] = (TN)th;
+        else for (int v = 0; v < V; ++v) pb[v] += th * phiS[(k0 + k) * V + v];
+      }
+    }
+    if (mode == 2) for (int v = 0; v < V; ++v) out[n * ldo + v] = (TN)pb[v];
+    if (mode == 3) for (int v = 0; v < V; ++v) { const double w = (double)ws[n * V + v]; s_wlp += w * (double)t_log<T>(pb[v]); s_w += w; }
   }
   if (mode == 3) {
     const double a = block_sum(s_wlp, scratch), b = block_sum(s_w, scratch);

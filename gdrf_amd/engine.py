@@ -57,15 +57,17 @@ class Engine:
         self.pure_fp32 = bool(pure_fp32) and dtype == torch.float32
         self.ctx = ctx
         self.stores_t = bool(self.lib.gdrf_stores_t(self.ctx))
-        # arithmetic of the f32 GEMM-shaped contractions: "bf16x6" = exact-split emulation on the bf16 matrix path (f32-level
-        # error, csrc/gemm_bf16x6.h), "f32" = native f32 MFMA; "auto" = bf16x6 wherever it applies (float32 arrays, dense Wbar)
-        if mfma_mode not in ("auto", "f32", "bf16x6"):
-            raise ValueError("mfma_mode must be 'auto', 'f32' or 'bf16x6'")
+        # arithmetic of the f32 GEMM-shaped contractions (csrc/gemm_split.h): "f16x3" = two block-scaled fp16 pieces per operand,
+        # 3 products; "bf16x6" = three bf16 pieces, 6 products (both: f32 accumulation on the 16-bit matrix path, error held to
+        # the native f32 MFMA kernels'); "f32" = native f32 MFMA.  "auto" = f16x3 wherever it applies (float32 arrays with the
+        # f64 solve - which bounds |W| by sqrt(variance) -, dense Wbar), bf16x6 for the all-fp32 arithmetic, else f32.
+        if mfma_mode not in ("auto", "f32", "bf16x6", "f16x3"):
+            raise ValueError("mfma_mode must be 'auto', 'f32', 'bf16x6' or 'f16x3'")
         if mfma_mode == "auto":
-            mfma_mode = "bf16x6" if (dtype == torch.float32 and not self.stores_t) else "f32"
+            mfma_mode = "f32" if (dtype != torch.float32 or self.stores_t) else ("bf16x6" if self.pure_fp32 else "f16x3")
         self.mfma_mode = mfma_mode
-        if mfma_mode == "bf16x6":
-            _lib.check(self.lib.gdrf_set_mfma_mode(self.ctx, 1), "gdrf_set_mfma_mode")
+        if mfma_mode != "f32":
+            _lib.check(self.lib.gdrf_set_mfma_mode(self.ctx, {"bf16x6": 1, "f16x3": 2}[mfma_mode]), "gdrf_set_mfma_mode")
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
         zl = (C.c_int64 * 2)()
@@ -133,7 +135,7 @@ class Engine:
         return self.PARAM_NAMES + extra
 
     def named_views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        return {n: self.view(n, buf) for n in self.PARAM_NAMES}
+        return {n: self.view(n, buf) for n in self.param_names}
 
     def set_inducing_points(self, Z: torch.Tensor):
         Z = Z.to(device=self.device, dtype=self.dtype).contiguous()
@@ -221,15 +223,21 @@ class Engine:
                                           _stream_ptr(self.device)), "gdrf_fill_eps")
         return out
 
+    def ll_const_dev(self, ws: torch.Tensor) -> torch.Tensor:
+        """Device scalar holding the data-only constant of Multinomial.log_prob for ``ws`` (no host sync).  Cached for the
+        IDENTICAL tensor object only (held here, so its storage cannot be handed to another mini-batch) at the same
+        ``_version``: a fresh same-shaped mini-batch (train_script.py:461-465) is always recomputed."""
+        c = self._ll_cache
+        if c is not None and c[0] is ws and c[1] == ws._version:
+            return c[2]
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.gdrf_ll_const_dev(self.ctx, ws.data_ptr(), ws.shape[0], out.data_ptr(), _stream_ptr(self.device)),
+                   "gdrf_ll_const_dev")
+        self._ll_cache = (ws, ws._version, out)
+        return out
+
     def ll_const(self, ws: torch.Tensor) -> float:
-        key = (ws.data_ptr(), ws._version, tuple(ws.shape))
-        if self._ll_cache is not None and self._ll_cache[0] == key:
-            return self._ll_cache[1]
-        out = C.c_double()
-        _lib.check(self.lib.gdrf_ll_const(self.ctx, ws.data_ptr(), ws.shape[0], C.byref(out), _stream_ptr(self.device)),
-                   "gdrf_ll_const")
-        self._ll_cache = (key, out.value)
-        return out.value
+        return float(self.ll_const_dev(ws).item())
 
     def jitter_total(self, level: int) -> float:
         return sum(self.jitter * (10 ** n) for n in range(level + 1))
@@ -278,7 +286,10 @@ class Engine:
             raise ValueError(f"eps must be a contiguous ([P,]{self.K},{n}) {self.dtype} tensor on {self.device}")
         s = _stream_ptr(self.device)
         self.refresh_inducing()
-        llc = self.ll_const(ws) if ll_const is None else ll_const
+        if ll_const is None:
+            llc = self.ll_const_dev(ws)
+        else:
+            llc = torch.full((1,), float(ll_const), dtype=torch.float64, device=self.device)
         ng = float(n if n_global is None else n_global)
         guess = self._guess_level if (force_level is None and self.speculate) else None
         if guess is None:
@@ -374,12 +385,14 @@ class Engine:
         elif P > 1:
             self.red_T.copy_(torch.stack(Ts).mean(0))
             self.red_d.copy_(torch.stack(ds).mean(0))
+        self.red_d[7:8].copy_(llc)                   # the data constant is a sum over observations too; stays on the device
         if dist_on:
-            self.red_d[7] = llc                      # the data constant is a sum over observations too
+            # ONE collective per step: the doubles of red_d ride in the tail of the flat payload (exactly in float64 contexts,
+            # as four 12-bit-mantissa float pieces each in float32 ones, whose sums over <= 8 ranks are exact in float32)
+            _lib.check(self.lib.gdrf_payload_pack(self.ctx, self.red_T.data_ptr(), self.red_d.data_ptr(), s), "gdrf_payload_pack")
             dist.all_reduce(self.red_T, group=pg)    # RCCL over xGMI (backend "nccl" on ROCm)
-            dist.all_reduce(self.red_d, group=pg)
-            llc = None
-        self._finish(ng, llc)
+            _lib.check(self.lib.gdrf_payload_unpack(self.ctx, self.red_T.data_ptr(), self.red_d.data_ptr(), s), "gdrf_payload_unpack")
+        self._finish(ng, None)
 
     def _distributed(self) -> bool:
         if self.pg is None:

@@ -116,7 +116,7 @@ class SparseMultinomialGDRF:
         self.device = torch.device(device)
         self.dtype = dtype
         self._pure_fp32 = bool(pure_fp32)
-        self._mfma_mode = mfma_mode          # Engine(mfma_mode=...): "auto" | "f32" | "bf16x6"
+        self._mfma_mode = mfma_mode          # Engine(mfma_mode=...): "auto" | "f32" | "bf16x6" | "f16x3"
         self._kernel = kernel
         if kernel.input_dim != self._n_dims:
             raise ValueError("kernel.input_dim does not match the world's dimensionality")

@@ -43,10 +43,10 @@ class PyroOptimLike:
     def _step(self):
         e = self._engine
         a = self.args
+        if self.mode == "clippedadam":
+            self.lr *= float(a["lrd"])         # pyro's ClippedAdam decays lr BEFORE it forms step_size
         e.adam(self.mode, self.lr, betas=tuple(a["betas"]), eps=float(a["eps"]),
                weight_decay=float(a.get("weight_decay", 0.0)), clip=float(a.get("clip_norm", 10.0)))
-        if self.mode == "clippedadam":
-            self.lr *= float(a["lrd"])
 
     def get_state(self) -> dict:
         e = self._engine
@@ -54,7 +54,7 @@ class PyroOptimLike:
             return self._pending_state or {}
         m, v = e.named_views(e.exp_avg), e.named_views(e.exp_avg_sq)
         return {name: {"step": e.opt_step, "exp_avg": m[name].detach().clone(), "exp_avg_sq": v[name].detach().clone(),
-                       "lr": self.lr} for name in e.PARAM_NAMES}
+                       "lr": self.lr} for name in e.param_names}
 
     def set_state(self, state: dict):
         e = self._engine

@@ -8,11 +8,14 @@
  * Conventions: every function returns 0 on success, < 0 on a HIP/argument error (message from
  * gdrf_last_error()); pointers named *_dev are borrowed device pointers that the caller keeps
  * alive until the stream has been synchronised; `stream` is a hipStream_t passed as void*;
- * no exceptions cross the ABI; one host thread per context.  kernel_id: 0 RBF, 1 Matern52, 2 Matern32, 3 Exponential.
+ * no exceptions cross the ABI; one host thread per context.  kernel_id: 0 RBF, 1 Matern52, 2 Matern32, 3 Exponential,
+ * 4 RationalQuadratic.
  * dtype fixes the element type of every "void*" real array below:
- *   GDRF_F32 (0)      float arrays.  The K-fold contractions run on f32 MFMA; the ill-conditioned pieces (K_uu, its
- *                     Cholesky factor and inverse, the solve W = K_nm L^-T, its backward and the M x M epilogue) run
- *                     in f64, because the fp32 solve cancels terms |L^-1||k| >> |w| (DESIGN.md "precision").
+ *   GDRF_F32 (0)      float arrays.  The K-fold contractions are f32 GEMMs evaluated on the matrix cores in the arithmetic
+ *                     gdrf_set_mfma_mode() selects (native f32 MFMA, or split operands on the 16-bit matrix path with f32
+ *                     accumulation and f32-level error); the ill-conditioned pieces (K_uu, its Cholesky factor and inverse,
+ *                     the solve W = K_nm L^-T, its backward and the M x M epilogue) run in f64, because the fp32 solve
+ *                     cancels terms |L^-1||k| >> |w| (DESIGN.md "precision").
  *   GDRF_F64 (1)      double arrays, everything f64.
  *   GDRF_F32_PURE (2) float arrays, everything f32 (the reference's literal .float() arithmetic; for A/B runs).
  */
@@ -45,10 +48,16 @@ enum { GDRF_STORE_T_OFF = 0, GDRF_STORE_T_ON = 1, GDRF_STORE_T_AUTO = 2 };
 int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id, int store_t);
 int gdrf_stores_t(const gdrf_ctx* ctx);
 /* Arithmetic of the four f32 GEMM-shaped contractions of the step (tt = |S_k^T w|^2, Wbar, A_k = W^T diag(vbar_k) W,
- * G^T = W^T Wbar) in float contexts: 0 = v_mfma_f32_16x16x4_f32 (native f32 MFMA), 1 = exact-split emulation on
- * v_mfma_f32_16x16x32_bf16 (each f32 operand as 3 bf16 pieces, the 6 cross products of weight >= 2^-16, f32
- * accumulation: f32-level error at 16/6 of the f32 MFMA rate; gemm_bf16x6.h).  Mode 1 needs float arrays and the dense
- * Wbar form (GDRF_STORE_T_OFF); a fresh context is in mode 0, gdrf_amd.Engine selects 1 for float32 by default. */
+ * G^T = W^T Wbar) in float contexts (csrc/gemm_split.h):
+ *   0  v_mfma_f32_16x16x4_f32 (native f32 MFMA);
+ *   1  "bf16x6": each f32 operand as 3 bf16 pieces, the 6 cross products of weight >= 2^-16 on v_mfma_f32_16x16x32_bf16,
+ *      f32 accumulation: 16/6 of the f32 MFMA rate;
+ *   2  "f16x3": each f32 operand, times one power-of-two block scale that puts its largest magnitude below 2^15, as 2 fp16
+ *      pieces (22-23 significand bits), the 3 cross products hh + hl + lh on v_mfma_f32_16x16x32_f16, f32 accumulation, the
+ *      scales undone in the epilogues: 16/3 of the f32 MFMA rate.
+ * Modes 1 and 2 are held to the error of mode 0 against fp64 products of the same inputs (tests/test_gpu_parity.py).  They
+ * need float arrays and the dense Wbar form (GDRF_STORE_T_OFF); a fresh context is in mode 0, gdrf_amd.Engine selects 2 for
+ * float32 with the f64 solve by default. */
 int gdrf_set_mfma_mode(gdrf_ctx* ctx, int mode);
 int gdrf_get_mfma_mode(const gdrf_ctx* ctx);
 /* whiten = 0: the unwhitened branch of pyro's gp.util.conditional (gdrf/models/sparse_gdrf.py:30,175-185: the
@@ -82,6 +91,12 @@ void gdrf_ctx_destroy(gdrf_ctx* ctx);
 int gdrf_param_layout(const gdrf_ctx* ctx, int64_t out[7]);
 /* Per-step all-reduce payload: out = {off_ubar, off_phibar, off_A, off_GT, total_T, total_d}. */
 int gdrf_red_layout(const gdrf_ctx* ctx, int64_t out[6]);
+/* The step's ONE collective ("one ncclAllReduce(sum) per step over a flat buffer"): gdrf_payload_pack copies the
+ * 8 + M*D doubles of red_d into the tail of red_T (total_T of gdrf_red_layout includes it) in red_T's element type - as they
+ * are for double contexts, as four float pieces each (12 + 12 + 12 + 24 mantissa bits, so their sums over <= 8 ranks are exact)
+ * for float ones -; the caller all-reduces red_T alone and gdrf_payload_unpack restores red_d from the reduced tail. */
+int gdrf_payload_pack(gdrf_ctx* ctx, void* red_T_dev, const double* red_d_dev, void* stream);
+int gdrf_payload_unpack(gdrf_ctx* ctx, const void* red_T_dev, double* red_d_dev, void* stream);
 /* Dirichlet concentration (K*V doubles, host): validate_dirichlet_param, gdrf/models/utils.py:6-24. */
 int gdrf_set_dirichlet(gdrf_ctx* ctx, const double* alpha_host);
 
@@ -97,6 +112,9 @@ int gdrf_fill_eps(gdrf_ctx* ctx, uint64_t seed, uint32_t step, int64_t n_offset,
 /* sum_n [lgamma(sum_v w+1) - sum_v lgamma(w+1)]: the data-only part of Multinomial.log_prob
  * (gdrf/models/sparse_gdrf.py:363-372).  Synchronises the stream. */
 int gdrf_ll_const(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* out_host, void* stream);
+/* The same constant written to a device double (e.g. red_d + 7, where gdrf_step_finish reads it when its ll_const argument
+ * is NaN), without synchronising: a mini-batch step (gdrf/train_script.py:461-465) then needs no host round trip for it. */
+int gdrf_ll_const_dev(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* out_dev, void* stream);
 
 /* jittercholesky's retry loop (gdrf/models/utils.py:27-40) on kernel(inducing_points)
  * (gdrf/models/sparse_gdrf.py:327-328,382-383): nlev (<= 8) attempts with the cumulative jitters
@@ -150,8 +168,8 @@ int gdrf_ws_elem_size(gdrf_ctx* ctx, int which);
 int gdrf_ws_copy(gdrf_ctx* ctx, int which, void* dst_dev, int64_t nelem, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).  Slots:
- * 0 factorize, 1 k_nm, 2 transforms+B_k, 3 fwd_w, 4 loc (W U^T), 5 fwd_t, 6 elbo_rows, 7 bwd_wbar,
- * 8 bwd_knm, 9 tn_sym (A_k), 10 tn_gt, 11 slab reductions, 12 ubar, 13 step_finish, 14 adam, 15 factorize (slot 0 = probes).
+ * 0 probe, 1 k_nm, 2 transforms+B_k, 3 fwd_w, 4 loc (W U^T), 5 fwd_t, 6 elbo_rows, 7 bwd_wbar,
+ * 8 bwd_knm, 9 tn_sym (A_k), 10 tn_gt, 11 slab reductions, 12 ubar, 13 step_finish, 14 adam, 15 factorize.
  * gdrf_get_timing synchronises on the recorded events and returns accumulated ms and counts. */
 int gdrf_set_timing(gdrf_ctx* ctx, int enable);
 int gdrf_get_timing(gdrf_ctx* ctx, double* ms_out, int64_t* count_out, int nslots);

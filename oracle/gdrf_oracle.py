@@ -275,6 +275,50 @@ class RefShapedGDRF:
                                ll=float(ll.detach()))
         return -elbo
 
+    def row_terms(self, eps: torch.Tensor, xs, ws, Luu=None) -> torch.Tensor:
+        """Sum over the given rows of every per-observation term of the ELBO, unscaled: lp_mu + ll - lq_mu.
+        The guide's and the model's ``conditional`` have identical values (quirk Q4), so it is evaluated once here; used by
+        :meth:`loss_chunked` to evaluate sizes whose N x M x K intermediate does not fit the host at once."""
+        xs = torch.as_tensor(xs).to(self.dtype)
+        ws = torch.as_tensor(ws).to(torch.int32)
+        eps = torch.as_tensor(eps).to(self.dtype)
+        c = self.constrained()
+        Luu = self._luu(c) if Luu is None else Luu
+        f_loc, f_var = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
+                                   c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"], self.whiten)
+        if self.mean_function is not None:
+            f_loc = f_loc + self.mean_function(xs)
+        mu = f_loc + f_var * eps
+        lq_mu = Normal(f_loc, f_var).log_prob(mu).sum()
+        lp_mu = Normal(f_loc, f_var + c["noise"]).log_prob(mu).sum()
+        probs = torch.matmul(torch.softmax(mu, -2).transpose(-2, -1), c["phi"])
+        ll = Multinomial(probs=probs, validate_args=False).log_prob(ws).sum()
+        return lp_mu + ll - lq_mu
+
+    def loss_chunked(self, eps, xs, ws, n_global: int, chunk: int = 25000, grad_names=("u_loc", "phi_unc")):
+        """The loss of :meth:`loss` evaluated in row chunks (every term but the Dirichlet one is a sum over observations),
+        with autograd gradients of the parameters in ``grad_names`` accumulated chunk by chunk (only parameters the
+        predictive variance does not depend on are cheap: u_loc, phi_unc, log_noise).  Returns (loss, {name: grad})."""
+        N = xs.shape[0]
+        c = self.constrained()
+        with torch.no_grad():
+            Luu = self._luu(c)
+        total = 0.0
+        grads = {k: torch.zeros_like(self.params[k]) for k in grad_names}
+        ps = [self.params[k] for k in grad_names]
+        for lo in range(0, N, chunk):
+            hi = min(N, lo + chunk)
+            t = self.row_terms(eps[:, lo:hi], xs[lo:hi], ws[lo:hi], Luu=Luu)
+            for k, g in zip(grad_names, torch.autograd.grad(t, ps, allow_unused=True)):
+                if g is not None:
+                    grads[k] += g
+            total += float(t.detach())
+        lp_phi = Dirichlet(self.alpha).log_prob(self.constrained()["phi"]).sum()
+        if "phi_unc" in grads:
+            grads["phi_unc"] += torch.autograd.grad(lp_phi, self.params["phi_unc"])[0]
+        scale = 1.0 / n_global
+        return -scale * (total + float(lp_phi.detach())), {k: -scale * g for k, g in grads.items()}
+
     def renyi_loss(self, eps: torch.Tensor, alpha: float = 0.0, **kw) -> torch.Tensor:
         """pyro.infer.RenyiELBO(alpha, num_particles=P) (pyro-ppl 1.8.0, third-party; published estimator, Li & Turner 2016):
         with the scaled per-particle ELBOs e_p,  loss = -(logsumexp((1 - alpha) e_p) - log P) / (1 - alpha).  All sites are
@@ -405,9 +449,11 @@ def _np_transforms(params):
     return (np.exp(params["log_lengthscale"]), np.exp(params["log_variance"]), np.exp(params["log_noise"]), S, phi, K, M)
 
 
-def fused_local(kind, xs, ws, Z, params: Dict[str, np.ndarray], eps, jitter_total_: float):
+def fused_local(kind, xs, ws, Z, params: Dict[str, np.ndarray], eps, jitter_total_: float, heavy: bool = True):
     """Everything of one step that is a sum over THIS shard's observations: the all-reduce payload
-    (what gdrf_step_local writes to red_T / red_d) plus the stage values (aux)."""
+    (what gdrf_step_local writes to red_T / red_d) plus the stage values (aux).  heavy=False stops after the row-local
+    backward (no Wbar / A_k / G / K_nm sums: the N M^2 K backward contractions), which is what a chunked evaluation of the
+    headline size can afford on the host; the payload then lacks those entries."""
     xs = np.asarray(xs)
     dt = xs.dtype
     ws_f = np.asarray(ws).astype(dt)
@@ -421,7 +467,7 @@ def fused_local(kind, xs, ws, Z, params: Dict[str, np.ndarray], eps, jitter_tota
     W = Knm @ Linv.T
     q = (W * W).sum(-1)
     loc = U @ W.T                                         # (K,N)
-    T = np.einsum("ni,kij->knj", W, S)                    # (K,N,M)
+    T = np.matmul(W[None], S)                             # (K,N,M): T_k = W S_k
     tt = (T * T).sum(-1)
     a = (var - q > 0).astype(dt)
     v = a * (var - q) + tt
@@ -448,6 +494,10 @@ def fused_local(kind, xs, ws, Z, params: Dict[str, np.ndarray], eps, jitter_tota
     dc_deta = -1 / s + eps ** 2 * r ** 2 / s
     vbar = mubar * eps + dc_dv
     locbar = mubar
+    if not heavy:
+        payload = dict(site=float(c_site.sum()), llw=llw, ll_const=ll_const, noise_g=float(dc_deta.sum()),
+                       var_direct=float((a * vbar.sum(0)).sum()), ubar=locbar @ W, phibar_lik=theta @ pbar)
+        return payload, dict(q=q, loc=loc, tt=tt, var=v, mu=mu, theta=theta, vbar=vbar, locbar=locbar, L=L, Linv=Linv, phi=phi, S=S)
     B = np.einsum("kij,klj->kil", S, S)                   # S_k S_k^T
     Wbar = locbar.T @ U - 2 * (a * vbar.sum(0))[:, None] * W
     for k in range(K):

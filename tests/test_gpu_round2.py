@@ -1,0 +1,165 @@
+"""GPU parity tests added in round 2: the streaming mini-batch regime (gdrf/train_script.py:394-465), optimizer details,
+shapes beyond the first round's limits, and the packed all-reduce payload."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import dev, engine_from_oracle, make_oracle, relerr
+from gdrf_amd import _lib
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL_VS_TORCH = 1e-6          # torch evaluates lgamma(int32 counts) in float32 (tests/test_gpu_parity.py)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64])
+def test_streaming_minibatch_steps_follow_the_oracle(n):
+    """svi.step on n rows with the 1/len(full data) scale (quirk Q9), five consecutive steps on DIFFERENT same-shaped
+    mini-batches: every loss (including the data-only Multinomial constant of that batch) and the parameters after the
+    five Adam steps match the reference-shaped oracle."""
+    m, _ = make_oracle(dtype=torch.float64, jitter=1e-6, optimizer="adam", lr=1e-2, W=24, H=16, V=15, K=3, n_points=(5, 4))
+    eng = engine_from_oracle(m, n_cap=64)
+    g = torch.Generator().manual_seed(11)
+    N = m.N
+    for step in range(5):
+        sel = torch.randperm(N, generator=g)[:n]
+        xs_b, ws_b = m.xs[sel], m.ws[sel]
+        eps = torch.randn(m.K, n, generator=g, dtype=torch.float64)
+        loss_ref = m.step(eps, xs=xs_b, ws=ws_b, n_global=N)
+        # fresh device tensors every step, as train_script.py:461-465 builds them: the allocator may hand back the same storage
+        eng.loss_and_grads(dev(xs_b, eng), dev(ws_b, eng, torch.int32), dev(eps, eng), n_global=N)
+        eng.adam("adam", 1e-2)
+        out = eng.read_out()
+        assert abs(out["loss"] - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref), (n, step, out["loss"], loss_ref)
+    for name in eng.PARAM_NAMES:
+        assert relerr(eng.view(name).cpu().numpy(), m.params[name].detach().numpy()) < 1e-7, (n, name)
+
+
+def test_two_same_shaped_minibatches_get_their_own_multinomial_constant():
+    """the data-only constant was cached by (data_ptr, version, shape); a second mini-batch living in recycled
+    storage took the first one's constant.  Through the model surface, evaluate_loss on two batches, each against the oracle."""
+    from gdrf_amd import poutine
+    from gdrf_amd.infer import SVI, Trace_ELBO
+    from gdrf_amd.kernels import RBF
+    from gdrf_amd.models import SparseMultinomialGDRF
+    from gdrf_amd.optim import Adam
+    m, _ = make_oracle(dtype=torch.float64, jitter=1e-6, perturb=False, W=20, H=10, V=12, K=3, n_points=(4, 3), lengthscale=0.2)
+    device = "cuda:0"
+    xs, ws = m.xs.to(device), m.ws.to(device)
+    model = SparseMultinomialGDRF(xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=RBF(2, torch.tensor(0.2), torch.tensor(25.0)),
+                                  num_observation_categories=12, num_topic_categories=3, dirichlet_param=0.01, n_points=[4, 3],
+                                  fixed_inducing_points=True, inducing_init="grid", maxjitter=15, jitter=1e-6, device=device,
+                                  dtype=torch.float64)
+    sc = poutine.scale(scale=1.0 / m.N)
+    svi = SVI(model=sc(model.model), guide=sc(model.guide), optim=Adam({"lr": 1e-3}), loss=Trace_ELBO())
+    g = torch.Generator().manual_seed(2)
+    for rows in ([0, 1, 2, 3], [100, 150, 17, 60]):
+        eps = torch.randn(3, 4, generator=g, dtype=torch.float64)
+        xb, wb = xs[rows].clone(), ws[rows].clone()           # same shape, new storage (possibly the block just freed)
+        got = svi.evaluate_loss(xs=xb, ws=wb, eps=eps)
+        ref = float(m.loss(eps, xs=m.xs[rows], ws=m.ws[rows], n_global=m.N).detach())
+        assert abs(got - ref) <= LOSS_TOL_VS_TORCH * abs(ref), (rows, got, ref)
+        del xb, wb
+
+
+def test_clipped_adam_decays_lr_before_the_update():
+    """pyro's ClippedAdam multiplies lr by lrd BEFORE forming step_size: three steps with lrd = 0.9."""
+    from gdrf_amd.optim import ClippedAdam
+    m, _ = make_oracle(dtype=torch.float64, jitter=1e-6, optimizer="clippedadam", lr=1e-2)
+    for name, p in m.params.items():
+        m._get_opt(name, p).lrd = 0.9
+    eng = engine_from_oracle(m)
+    opt = ClippedAdam({"lr": 1e-2, "lrd": 0.9})
+    opt._bind(eng)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        eps = torch.randn(m.K, m.N, generator=g, dtype=torch.float64)
+        m.step(eps)
+        eng.loss_and_grads(xs, ws, dev(eps, eng))
+        opt._step()
+    assert abs(opt.lr - 1e-2 * 0.9 ** 3) < 1e-15
+    for name in eng.PARAM_NAMES:
+        assert relerr(eng.view(name).cpu().numpy(), m.params[name].detach().numpy()) < 1e-8, name
+
+
+def test_optimizer_state_round_trip_carries_the_inducing_inputs():
+    """get_state/set_state (train_script.py:348,495) cover every learnt block, also the ones only some configurations carry."""
+    from gdrf_amd.optim import Adam
+    m, _ = make_oracle(dtype=torch.float64, jitter=1e-6, learn_inducing=True, random_inducing=True, lr=1e-2)
+    eng = engine_from_oracle(m)
+    opt = Adam({"lr": 1e-2}); opt._bind(eng)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(2):
+        eng.loss_and_grads(xs, ws, dev(torch.randn(m.K, m.N, generator=g, dtype=torch.float64), eng)); opt._step()
+    st = opt.get_state()
+    assert "inducing_unc" in st and float(st["inducing_unc"]["exp_avg_sq"].abs().max()) > 0
+    eng2 = engine_from_oracle(m)
+    eng2.params.copy_(eng.params)
+    opt2 = Adam({"lr": 1e-2}); opt2._bind(eng2); opt2.set_state(st)
+    eps = dev(torch.randn(m.K, m.N, generator=g, dtype=torch.float64), eng)
+    for e, o in ((eng, opt), (eng2, opt2)):
+        e.loss_and_grads(xs, ws, eps); o._step()
+    assert torch.equal(eng.params, eng2.params)
+
+
+def test_more_than_32_topics():
+    """num_topics is unbounded in the reference (train_script.py:111); K = 40 runs the generic row kernels."""
+    m, eps = make_oracle(dtype=torch.float64, jitter=1e-6, W=15, H=9, V=11, K=40, n_points=(4, 3))
+    eng = engine_from_oracle(m)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    eng.loss_and_grads(xs, ws, dev(eps, eng))
+    out = eng.read_out()
+    m.force_jitter_level = eng.last_jitter_level
+    loss_ref, grads_ref = m.loss_and_grads(eps)
+    assert abs(out["loss"] - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref)
+    gv = eng.named_views(eng.grads)
+    for name in eng.PARAM_NAMES:
+        assert relerr(gv[name].cpu().numpy(), grads_ref[name].numpy()) < 1e-7, name
+    assert relerr(eng.predict(xs, 1).cpu().numpy(), m.topic_probs().numpy()) < 1e-9
+    assert relerr(eng.predict(xs, 2).cpu().numpy(), m.word_probs().numpy()) < 1e-9
+    assert relerr(eng.predict(xs, 0).cpu().numpy(), m.log_topic_probs().numpy()) < 1e-9
+    s = eng.predict(xs, 3, ws).cpu().numpy()
+    assert abs(float(np.exp(-s[0] / s[1])) - float(m.perplexity())) < 1e-8 * float(m.perplexity())
+
+
+def test_large_vocabulary_shrinks_the_row_block_and_oversize_fails_loudly():
+    m, eps = make_oracle(dtype=torch.float64, jitter=1e-6, W=12, H=9, V=300, K=5, n_points=(4, 3))
+    eng = engine_from_oracle(m)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    eng.loss_and_grads(xs, ws, dev(eps, eng))
+    out = eng.read_out()
+    m.force_jitter_level = eng.last_jitter_level
+    loss_ref, grads_ref = m.loss_and_grads(eps)
+    assert abs(out["loss"] - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref)
+    assert relerr(eng.named_views(eng.grads)["phi_unc"].cpu().numpy(), grads_ref["phi_unc"].numpy()) < 1e-7
+    m2, eps2 = make_oracle(dtype=torch.float64, jitter=1e-6, W=6, H=5, V=2500, K=5, n_points=(3, 2))
+    eng2 = engine_from_oracle(m2)
+    with pytest.raises(_lib.GdrfHipError, match="too large"):
+        eng2.loss_and_grads(dev(m2.xs, eng2), dev(m2.ws, eng2, torch.int32), dev(eps2, eng2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_packed_payload_sums_like_float64(dtype):
+    """The doubles of red_d travel in the tail of the flat payload (one all-reduce per step): emulate a 4-rank sum of the
+    packed tails in the payload's element type and compare with the float64 sum."""
+    m, _ = make_oracle(dtype=dtype, jitter=1e-4)
+    eng = engine_from_oracle(m)
+    lib, s = eng.lib, torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    nd = eng.red_d.numel()
+    vals = [(torch.randn(nd, generator=g, dtype=torch.float64) * 10.0 ** torch.randint(-3, 9, (nd,), generator=g)).to(eng.device)
+            for _ in range(4)]
+    acc = torch.zeros_like(eng.red_T)
+    for v in vals:
+        eng.red_T.zero_(); eng.red_d.copy_(v)
+        _lib.check(lib.gdrf_payload_pack(eng.ctx, eng.red_T.data_ptr(), eng.red_d.data_ptr(), s), "pack")
+        acc += eng.red_T                                   # what the all-reduce does, in the payload's dtype
+    eng.red_d.zero_()
+    _lib.check(lib.gdrf_payload_unpack(eng.ctx, acc.data_ptr(), eng.red_d.data_ptr(), s), "unpack")
+    ref = torch.stack(vals).sum(0)
+    scale = torch.stack(vals).abs().max(0).values
+    err = ((eng.red_d - ref).abs() / scale).max().item()
+    assert err < (1e-15 if dtype == torch.float64 else 1e-12), err
