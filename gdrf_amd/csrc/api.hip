@@ -4,6 +4,7 @@
 #include "gemm_nt.h"
 #include "gemm_tn.h"
 #include "gemm_split.h"
+#include "gemm_tn_topics.h"
 #include "kernels_mm.h"
 #include "kernels_n.h"
 
@@ -166,6 +167,28 @@ static int tn_nsplit_gt(const gdrf_ctx* c, int64_t n, int BR) {
   return best;
 }
 
+// Row splits of the all-topics A_k kernel (gemm_tn_topics.h): one 512-thread workgroup per CU, tiles x topic groups x splits
+// workgroups; fill the 256 CUs' rounds, >= 16 chunks per split, at most 64 splits
+static bool tn_topics_on(const gdrf_ctx* c) {
+  if (c->split != 2) return false;
+  const char* e = getenv("GDRF_TN_TOPICS");
+  return !(e && e[0] == '0');
+}
+static int tn_topics_nsplit(const gdrf_ctx* c, int64_t n) {
+  if (const char* e = getenv("GDRF_TNT_NSPLIT")) { const int v = atoi(e); if (v > 0) return v; }
+  const int units = tnt_ntiles(c->Mp) * ((c->K + TNT_KT - 1) / TNT_KT);
+  int64_t maxs = (n + 16 * 32 - 1) / (16 * 32);
+  if (maxs > 64) maxs = 64;
+  if (maxs < 1) maxs = 1;
+  int best = 1; double best_eff = 0;
+  for (int ns = 1; ns <= maxs; ++ns) {
+    const double rounds = units * (double)ns / 256.0;
+    const double eff = rounds / std::ceil(rounds);
+    if (eff > best_eff + 0.01) { best_eff = eff; best = ns; }
+  }
+  return best;
+}
+
 int gdrf_ctx_create(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, int V, int D, int dtype, int kernel_id) {
   return gdrf_ctx_create_ex(out, device, n_cap, M, K, V, D, dtype, kernel_id, GDRF_STORE_T_OFF);
 }
@@ -221,7 +244,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
     if (store_t == GDRF_STORE_T_ON) { AL(c->Tst, tbytes) }
   }
   c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
-  if (c->esz == 4) c->nsplit_cap = std::max({c->nsplit_cap, tn_nsplit(c, n_cap, 32, 2), tn_nsplit_gt(c, n_cap, 32)});   // the bf16x6 TN form runs 2 workgroups per CU
+  if (c->esz == 4) c->nsplit_cap = std::max({c->nsplit_cap, tn_nsplit(c, n_cap, 32, 2), tn_nsplit_gt(c, n_cap, 32), 64});   // the split TN forms run 2 workgroups per CU; the all-topics form up to 64 splits
   AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
   c->ubar_blocks_cap = std::min<int64_t>(1025, (n_cap + 255) / 256);     // upper bound of ubar_blocks(n) over n <= n_cap
   AL(c->ubar_part, (size_t)c->ubar_blocks_cap * K * c->Mp * c->esz)
@@ -506,14 +529,43 @@ template <typename T, typename TS> struct Impl {
       ScopedTimer tm(c, 5, s);
       // topics per group: as many lower-triangular S^T piece panels (NP x ~0.6 Mp^2 halfwords each) as fit in 2 MB
       const double panel = 0.625 * 2.0 * SP::NP * (double)Mp * Mp;
-      const int KG = std::max(1, std::min(K, (int)(2.0 * 1024 * 1024 / panel)));
+      int KG = std::max(1, std::min(K, (int)(2.0 * 1024 * 1024 / panel)));
+      if (const char* e = getenv("GDRF_FWDT_KG")) { const int v = atoi(e); if (v > 0) KG = std::min(K, v); }   // tuning knob (tools/)
       // two row tiles per 512-thread workgroup (two phase-shifted wave groups, LDS-DMA staging): 6 operand images
       const int64_t pairs = (rtiles + 1) / 2;
       const int rt8 = (int)((pairs + 7) / 8);
-      FwdTSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, rt8, (const E*)c->STh, nb, (float*)c->tt, c->ldk, (const float*)c->ssc};
+      FwdTSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, rt8, (const E*)c->STh, nb, (float*)c->tt, c->ldk, (const float*)c->ssc, nullptr};
       constexpr int lds2 = 6 * SplitCfg<SP>::IMG * 2;
-      HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-      hipLaunchKernelGGL(fwd_t_split_2g_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
+      if (getenv("GDRF_STAMP")) {           // diagnostic: per-phase s_memtime stamps of one workgroup (tools/), never in a timed run
+        unsigned long long* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, 2 * 64 * 4 * 8)); HIPCHK(hipMemset(d, 0, 2 * 64 * 4 * 8));
+        a.stamps = d;
+        HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2 + 4096));
+        hipLaunchKernelGGL((fwd_t_split_2g_kernel<SP, true>), dim3((unsigned)(8 * K * rt8)), dim3(512), lds2 + 4096, s, a);
+        std::vector<unsigned long long> h(2 * 64 * 4);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost)); (void)hipFree(d);
+        for (int gpi = 0; gpi < 2; ++gpi) {
+          double sm = 0, sv = 0, sb = 0, so = 0; int cnt = 0; std::string line;
+          for (int t = 1; t < 40; ++t) {
+            const unsigned long long* q = &h[(gpi * 64 + t) * 4];
+            const long long m = q[1] - q[0], v = q[2] - q[1], b = q[3] - q[2], o = q[0] - h[(gpi * 64 + t - 1) * 4 + 3];
+            sm += m; sv += v; sb += b; so += o; ++cnt;
+            line += " " + std::to_string(m) + "/" + std::to_string(o);
+          }
+          fprintf(stderr, "fwd_t stamps group %d: mean mult %.0f vmcnt %.0f barrier %.0f other-group-phase %.0f | mult/other per chunk:%s\n", gpi, sm / cnt, sv / cnt,
+                  sb / cnt, so / cnt, line.c_str());
+        }
+        return 0;
+      }
+      const char* alt = getenv("GDRF_FWDT_ALTERNATING");          // A/B knob: the phase-alternating form
+      if (alt && alt[0] == '1') {
+        HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+        hipLaunchKernelGGL(fwd_t_split_2g_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
+      } else {
+        HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_cc_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+        hipLaunchKernelGGL(fwd_t_split_cc_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
+      }
       LAUNCHCHK("fwd_t_split");
       return 0;
     } else {
@@ -522,14 +574,14 @@ template <typename T, typename TS> struct Impl {
   }
 
   // C = Wh^T diag(scale) B over the observations on the 16-bit matrix path (f32 contexts only); A side = the pieces of W.
-  // sidx_b / sidx_b_stride: SplitLay pair index of the B operand's block scale (per batch); b_is_w: B is the unscaled f32 W (A_k)
+  // sidx_b / sidx_b_stride: SplitLay pair index of the block scale of the row-scaled B operand (per batch)
   template <class SP>
   static int tn_split(gdrf_ctx* c, const float* B, const float* scale, int64_t scale_bs, int64_t n, int64_t rps, int sym, float* slab,
-                      int nbatch, int ns, int ntiles, int sidx_b, int sidx_b_stride, int b_is_w, hipStream_t s) {
+                      int nbatch, int ns, int ntiles, int sidx_b, int sidx_b_stride, hipStream_t s) {
     if constexpr (std::is_same<T, float>::value) {
       using E = typename SP::E;
       TNSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns,
-                        (const float*)c->ssc, SplitLay{c->K}.w(), sidx_b, sidx_b_stride, b_is_w};
+                        (const float*)c->ssc, SplitLay{c->K}.w(), sidx_b, sidx_b_stride};
       constexpr int lds = 3 * SP::NP * 32 * 128 * 2;            // double-buffered A image + B image
       HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_split_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(gemm_tn_split_kernel<SP>, dim3((unsigned)(ntiles * nbatch * ns)), dim3(256), lds, s, a);
@@ -734,8 +786,8 @@ template <typename T, typename TS> struct Impl {
       { ScopedTimer tm(c, 10, ss);
         if (c->split) {
           const int ib = SplitLay{K}.wbar();
-          if ((rc = (c->split == 2 ? tn_split<SplitF16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ib, 0, 0, ss)
-                                   : tn_split<SplitBf16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ib, 0, 0, ss)))) return rc;
+          if ((rc = (c->split == 2 ? tn_split<SplitF16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ib, 0, ss)
+                                   : tn_split<SplitBf16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, (float*)slab_gt, 1, ns, c->nt * c->nt, ib, 0, ss)))) return rc;
         } else {
           hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * c->nt * ns)), dim3(256), TNCfg<T>::LDS_BYTES, ss, b);
         } }
@@ -779,17 +831,32 @@ template <typename T, typename TS> struct Impl {
       const int ns = std::min(tn_nsplit(c, n, BR, c->split ? 2 : 3), c->nsplit_cap);
       const int64_t rps = round_up((n + ns - 1) / ns, BR);
       TNArgs<T> a{P(c->W), Mp, P(c->W), Mp, P(c->vbar), ldk, n, rps, Mp, 1, P(c->slab), K, ns};
+      int red_ns = ns, red_qd = GDRF_TILE / 2;
       { ScopedTimer tm(c, 9, s);
-        if (c->split) {
+        if (tn_topics_on(c)) {
+          if constexpr (std::is_same<T, float>::value) {
+            const SplitLay SL{K};
+            const int nst = std::min(tn_topics_nsplit(c, n), c->nsplit_cap);
+            const int64_t rpst = round_up((n + nst - 1) / nst, 32);
+            const int ntl = tnt_ntiles(Mp), kgroups = (K + TNT_KT - 1) / TNT_KT;
+            TNTopicsArgs ta{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbar, ldk, n, rpst, Mp,
+                            (float*)c->slab, K, nst, ntl, (const float*)c->ssc, SL.w(), SL.v(0)};
+            constexpr int lds = 2 * 2 * 2 * 32 * 128 * 2 + 2 * TNT_KT * 32 * 4;
+            HIPCHK(hipFuncSetAttribute((const void*)tn_topics_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(tn_topics_f16_kernel, dim3((unsigned)(ntl * kgroups * nst)), dim3(512), lds, s, ta);
+            LAUNCHCHK("tn_topics");
+            red_ns = nst; red_qd = 32;
+          }
+        } else if (c->split) {
           const int ib = SplitLay{K}.v(0), ntl = c->nt * (c->nt + 1) / 2;
-          if ((rc = (c->split == 2 ? tn_split<SplitF16>(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, ntl, ib, 2, 1, s)
-                                   : tn_split<SplitBf16>(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, ntl, ib, 2, 1, s)))) return rc;
+          if ((rc = (c->split == 2 ? tn_split<SplitF16>(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, ntl, ib, 2, s)
+                                   : tn_split<SplitBf16>(c, (const float*)c->W, (const float*)c->vbar, ldk, n, rps, 1, (float*)c->slab, K, ns, ntl, ib, 2, s)))) return rc;
         } else {
           hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)(c->nt * (c->nt + 1) / 2 * K * ns)), dim3(256), TNCfg<T>::LDS_BYTES, s, a);
         } }
       { ScopedTimer tm(c, 11, s);
         dim3 gr((Mp + 255) / 256, Mp, K);
-        hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), ns, K, Mp, 1, redT + roff(c, 2)); }
+        hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), red_ns, K, Mp, 1, redT + roff(c, 2), red_qd); }
     }
     HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     LAUNCHCHK("reductions");

@@ -105,7 +105,8 @@ __global__ void split_scales_kernel(int f16, const Hyper* __restrict__ h, const 
       put(L.b(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_b(k)]), 15) : 1.0f);
       put(L.st(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_st(k)]), 15) : 1.0f);
     }
-    if (what & SPLIT_SC_V) put(L.v(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_v(k)]), 15) : 1.0f);
+    // operand of the A_k contraction: vbar_kn w_nj, bounded by max_n |vbar_kn| sqrt(variance) (same 4x headroom as W)
+    if (what & SPLIT_SC_V) put(L.v(k), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_v(k)]) * sqrtf((float)h->var), 13) : 1.0f);
   }
 }
 // mx[b] = max |x[b][i]|, i < n (grid: (blocks, batches)); mx zeroed by the caller
@@ -137,6 +138,22 @@ template <class SP> struct SplitCfg {
 // of the LDS cycles were bank conflicts).  ds_write_b128 (8 contiguous lanes = 2 whole rows = 32 distinct banks) is too.
 __device__ __forceinline__ int split_swz(int row) { return (row & 8) ? 3 : 0; }
 __device__ __forceinline__ int split_off(int row, int k) { return row * 32 + (((k >> 3) ^ split_swz(row)) << 3) + (k & 7); }
+
+// LDS-DMA issued from inline asm: hipcc then neither counts it nor - which is the point - drains it with a vmcnt(0) in front of the
+// next LDS read of the issuing wave (a builtin glds is a pending LDS write to the compiler, so every ds_read behind it waits for it:
+// the "prefetch" of the next chunk was retired BEFORE the current chunk's MFMAs).  The caller orders it by hand: it is older than
+// any register load issued after it, vmcnt retires in order, so the wait hipcc puts in front of the first use of such a load also
+// covers it; a barrier then publishes it to the other waves.  M0 is written in the statement that reads it and restored
+// (cdna_hip_programming.md 5.7).  lds_dst: wave-uniform LDS byte address; gsrc: this lane's 16 source bytes.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 
 // out[p * stride + i] = p-th piece of in[i] * scale; 4 elements per thread (n multiple of 4)
 template <class SP>
@@ -491,7 +508,13 @@ template <class SP> struct FwdTSplitArgs {
   const typename SP::E* STh; int64_t piece_stride;    // STh[p][k][i / 32][j][i % 32] = pieces of S_k[i][j] (k-blocked)
   float* tt; int64_t ldt;
   const float* sc;
+  unsigned long long* stamps;                 // diagnostic builds only (template parameter STAMP): [2 groups][phases][4] s_memtime values of one workgroup
 };
+__device__ __forceinline__ unsigned long long split_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
 
 // tt in the two-group LDS-DMA structure of bwd_wbar_split_kernel<2>: a 512-thread workgroup holds two adjacent row tiles of
 // one topic, one per wave group; both walk the same (column tile, reduction chunk) sequence, so the S_k^T chunk is staged once
@@ -501,7 +524,7 @@ template <class SP> struct FwdTSplitArgs {
 // Grid: 8 * K * rt8 with rt8 = ceil(row-tile pairs / 8).  Block map: XCD = blockIdx & 7 owns the pairs r * 8 + xcd; topics go
 // in groups of KG, group-major (every XCD first runs all its pairs for topics [0, KG), then [KG, 2 KG), ...) so that only KG
 // topics' S^T pieces are live in its 4 MB L2 at a time; the KG workgroups of one pair are adjacent.
-template <class SP>
+template <class SP, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void fwd_t_split_2g_kernel(FwdTSplitArgs<SP> g) {
   using CF = SplitCfg<SP>;
   using E = typename SP::E;
@@ -574,9 +597,12 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_2g_kernel(FwdTSplitArgs<SP
     for (int r = 0; r < 4; ++r) rs[a][r] = 0;
   f32x4 acc[4][4];
   const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);
+  const bool stamping = STAMP && blockIdx.x == 20000 && wave == 0 && lane == 0;
+  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(smem + 6 * IMG * 2);     // stamps stay in LDS until the end: a global store would sit in vmcnt
   auto mult = [&](int c) {
     int ct, kA; bool first, last;
     decode(c, ct, kA, first, last);
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); if (stamping && c < 64) lstamp[(gp * 64 + c) * 4 + 0] = split_stamp(); __builtin_amdgcn_sched_barrier(0); }
     if (first) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -615,7 +641,9 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_2g_kernel(FwdTSplitArgs<SP
           for (int r = 0; r < 4; ++r) rs[a][r] += cok ? acc[a][b][r] * acc[a][b][r] : 0.0f;
       }
     }
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); if (stamping && c < 64) lstamp[(gp * 64 + c) * 4 + 1] = split_stamp(); __builtin_amdgcn_sched_barrier(0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); if (stamping && c < 64) lstamp[(gp * 64 + c) * 4 + 2] = split_stamp(); __builtin_amdgcn_sched_barrier(0); }
   };
   auto phase_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -636,8 +664,156 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_2g_kernel(FwdTSplitArgs<SP
       dma_b(t + 1);
     }
     phase_barrier();
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); if (stamping && (ph & 1) == gp && t < 64) lstamp[(gp * 64 + t) * 4 + 3] = split_stamp(); __builtin_amdgcn_sched_barrier(0); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (STAMP) { if (stamping) for (int i = 0; i < 64 * 4; ++i) g.stamps[gp * 256 + i] = lstamp[gp * 256 + i]; }
+  // row sums: 16-lane groups, then the two waves of a group that share the rows, through LDS; the block scales come off here
+  float* rsum = reinterpret_cast<float*>(smem) + gp * GDRF_TILE;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[a][r] = group16_sum(rs[a][r]);
+  __syncthreads();
+  if (wc == 0 && lr == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rsum[wr * 64 + a * 16 + lg * 4 + r] = rs[a][r];
+  }
+  __syncthreads();
+  if (wc == 1 && lr == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rsum[wr * 64 + a * 16 + lg * 4 + r] += rs[a][r];
+  }
+  __syncthreads();
+  if (tid < GDRF_TILE) {
+    const int64_t m = m0 + tid;
+    const SplitLay SL{g.K};
+    const float un = g.sc[SL.w() + 1] * g.sc[SL.st(bz) + 1];
+    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = rsum[tid] * (un * un);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same contraction with BOTH wave groups multiplying in every phase ("concurrent" form).  fwd_t_split_2g_kernel alternates
+// the groups so that a SIMD's matrix pipe serves one wave at a time; measured per phase (s_memtime, f16x3, mid-launch
+// workgroup): multiply 1184 cycles for 768 cycles of MFMA, + ~110 (vmcnt) + ~180 (barrier) + ~400 (loop / address code) = ~1900
+// cycles during which the OTHER group's wave on that SIMD idles - the pipe is busy 40 %.  That structure paid off when a chunk was
+// 96 MFMAs (bf16x6) and staging went through ds_write; with 48 MFMAs per chunk the fixed per-phase costs dominate.  Here a chunk
+// is ONE phase for all 8 waves: the next chunk's LDS-DMAs are issued first (from asm: hipcc would otherwise retire them in front
+// of the fragment reads), then 16 fragment reads and 48 MFMAs per wave; the two waves of a SIMD share its pipe (2 x 768 cycles
+// per phase) and hide each other's read latency and address code; vmcnt(0) + one barrier end the phase.
+template <class SP>
+__global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP> g) {
+  using CF = SplitCfg<SP>;
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  constexpr int NP = SP::NP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = CF::IMG;
+  const int gp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  E* As = reinterpret_cast<E*>(smem) + gp * 2 * IMG;      // [2 buffers][NP][128][32] of this group
+  E* Bs = reinterpret_cast<E*>(smem) + 4 * IMG;           // [2 buffers][NP][128][32] shared
+  const int Mp = g.Mp;
+  const int nct = (Mp + GDRF_TILE - 1) / GDRF_TILE;
+  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned per_group = (unsigned)g.KG * (unsigned)g.rt8;
+  const int grp = (int)(idx / per_group);
+  const unsigned rem = idx - (unsigned)grp * per_group;
+  const int kg = min(g.KG, g.K - grp * g.KG);
+  const int64_t rtile = 2 * ((int64_t)(rem / (unsigned)kg) * 8 + xcd) + gp;
+  const int bz = grp * g.KG + (int)(rem % (unsigned)kg);
+  const int64_t m0 = rtile * GDRF_TILE;                        // a tile past the end runs on clamped rows; its tt is never stored
+
+  const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned a_lds = lds_addr(As), b_lds = lds_addr(Bs);
+  // chunk (ct, kA) -> buffer buf: A rows of this group (2 row blocks per wave), B columns (1 row block per wave of the 8)
+  auto dma = [&](int ct, int kA, int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbk = wave_u + 4 * i;
+      int64_t row = m0 + rbk * 16 + drow;
+      row = row < g.nrows ? row : 0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        glds16_asm(g.Wh + p * g.w_stride + row * Mp + kA + dq, a_lds + (unsigned)(((buf * NP + p) * CF::PIECE + rbk * 512) * 2));
+    }
+    {
+      const int rbk = wave_u + 4 * gp, row = rbk * 16 + drow;
+      const int col = (ct * GDRF_TILE + row < Mp) ? ct * GDRF_TILE + row : 0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        glds16_asm(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + dq,
+                   b_lds + (unsigned)(((buf * NP + p) * CF::PIECE + rbk * 512) * 2));
+    }
+  };
+  float rs[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[a][r] = 0;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);
+  int ct = 0, kA = 0, buf = 0;
+  dma(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  while (ct < nct) {
+    // the chunk after this one: next k block of the column tile, or the first one (k = 128 ct') of the next column tile
+    int ct1 = ct, kA1 = kA + CF::BK;
+    const bool last = kA1 >= Mp;
+    if (last) { ct1 = ct + 1; kA1 = ct1 * GDRF_TILE; }
+    if (ct1 < nct) dma(ct1, kA1, buf ^ 1);                    // buffers buf ^ 1 were last read one phase ago
+    const E* Ab = As + buf * IMG;
+    const E* Bb = Bs + buf * IMG;
+    V8 fb[NP][4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+    V8 faq[2][NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) faq[0][p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64) * 32 + frag);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      V8 (&fa)[NP] = faq[a & 1];
+      if (a + 1 < 4) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) faq[(a + 1) & 1][p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + (a + 1) * 16) * 32 + frag);
+      }
+#pragma unroll
+      for (int t = 0; t < SP::NPROD; ++t)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = SP::mma(fa[SP::pa(t)], fb[SP::pb(t)][b], acc[a][b]);
+    }
+    if (last) {                                                 // fold the finished column tile into the row sums, restart the accumulators
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool cok = ct * GDRF_TILE + wc * 64 + b * 16 + lr < Mp;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rs[a][r] += cok ? acc[a][b][r] * acc[a][b][r] : 0.0f;
+          acc[a][b] = f32x4{0, 0, 0, 0};
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's DMAs of the next chunk have landed (they had the whole phase)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ct = ct1; kA = kA1; buf ^= 1;
+  }
   // row sums: 16-lane groups, then the two waves of a group that share the rows, through LDS; the block scales come off here
   float* rsum = reinterpret_cast<float*>(smem) + gp * GDRF_TILE;
 #pragma unroll
@@ -690,8 +866,7 @@ template <class SP> struct TNSplitArgs {
   float* slab;                                         // [nsplit][nbatch][ncols][ncols]
   int nbatch, nsplit;
   const float* sc; int sidx_a;                         // block scales: pair index of the A pieces' scale,
-  int sidx_b, sidx_b_stride;                           //   of the B operand's (per batch: sidx_b + stride * b),
-  int b_times_a_scale;                                 //   1: the raw B data is unscaled W, it also takes A's scale (A_k)
+  int sidx_b, sidx_b_stride;                           //   of the (row-scaled) B operand's: sidx_b + stride * batch
 };
 
 __device__ __forceinline__ int tnb_code(int k) { return (((k >> 3) & 1) << 2) | (k & 3); }
@@ -745,8 +920,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   int64_t r1 = r0 + g.rows_per_split; if (r1 > g.nrows) r1 = g.nrows;
   const float* sc = g.scale ? g.scale + (int64_t)b * g.scale_bs : nullptr;
   const int sb = g.sidx_b + g.sidx_b_stride * b;
-  const float bscale = g.sc[sb] * (g.b_times_a_scale ? g.sc[g.sidx_a] : 1.0f);                              // applied to B at the split
-  const float unscale = g.sc[g.sidx_a + 1] * g.sc[sb + 1] * (g.b_times_a_scale ? g.sc[g.sidx_a + 1] : 1.0f);  // taken off the result
+  const float bscale = g.sc[sb];                               // applied to s[n] B[n][j] at the split
+  const float unscale = g.sc[g.sidx_a + 1] * g.sc[sb + 1];     // taken off the result
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -761,6 +936,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int nch = r0 < r1 ? (int)((r1 - r0 + 31) / 32) : 0;
+  const unsigned as_base = lds_addr(As) + (unsigned)wave_u * 1024u;
   auto dma_a = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -771,8 +947,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
       const int col = (i0 + c8 * 8 < g.ncols) ? i0 + c8 * 8 : 0;
 #pragma unroll
       for (int p = 0; p < NP; ++p)
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.Ah + p * g.a_stride + n * g.lda + col),
-                                         (lptr_t)(As + ((c & 1) * NP + p) * PIECE + blk * 512), 16, 0, 0);
+        glds16_asm(g.Ah + p * g.a_stride + n * g.lda + col, as_base + (unsigned)((((c & 1) * NP + p) * PIECE + 4 * i * 512) * 2));
     }
   };
   // B: 8 columns of a row per vector pair (q = tid&3 -> row 4*(khi + 4 i) + q, c8 = (tid>>2)&15, khi = tid>>6), 2 rows per thread:
@@ -780,18 +955,21 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
   const int sq = tid & 3, b_c8 = (tid >> 2) & 15, b_kh = tid >> 6;
   const bool b_ok = (j0 + b_c8 * 8) < g.ncols;                // ncols multiple of 32
   f32x4 rb[4];                                                 // [2 i + half]
-  float rs[2];
+  float rs[2], okf[2];
+  // Nothing here may depend on the loaded VALUES: a select or a scale applied to the prefetched registers at load time makes
+  // hipcc wait for the loads (vmcnt(0)) right here, in front of the MFMAs of the current chunk - the whole HBM latency exposed
+  // once per chunk.  Rows past the split / the end are read from a valid (clamped) row and annihilated by okf = 0 at the split.
   auto load_b = [&](int c) {
     const int64_t rbase = r0 + (int64_t)c * 32;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t n = rbase + 4 * (b_kh + 4 * i) + sq;
-      const bool ok = b_ok && n < r1;
-      const float* src = g.B + (ok ? n : r0) * g.ldb + (b_ok ? j0 + b_c8 * 8 : 0);
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-      rb[2 * i] = ok ? v0 : f32x4{0, 0, 0, 0};
-      rb[2 * i + 1] = ok ? v1 : f32x4{0, 0, 0, 0};
-      rs[i] = (sc && ok) ? sc[n] : 1.0f;
+      const int64_t nn = n < g.nrows ? n : g.nrows - 1;
+      const float* src = g.B + nn * g.ldb + (b_ok ? j0 + b_c8 * 8 : 0);
+      rb[2 * i] = *reinterpret_cast<const f32x4*>(src);
+      rb[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+      rs[i] = sc ? sc[nn] : 1.0f;
+      okf[i] = (b_ok && n < r1) ? 1.0f : 0.0f;
     }
   };
   // fragments: two transposing reads (k = 8 lg + q and + 4) of 4 rows x 16 columns each; seg = (8 lg + 4 h + q) * 32 + ((4 w + t) ^ code) * 4 + p
@@ -817,7 +995,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
     V8 pb[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float s = rs[i] * bscale;
+      const float s = rs[i] * okf[i] * bscale;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         E p[NP];

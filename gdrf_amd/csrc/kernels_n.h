@@ -1089,12 +1089,12 @@ __global__ void payload_unpack_kernel(const T* __restrict__ tail, int nd, double
 }
 // TN slabs: out[b][i][j] = sum_sp slab[sp][b][i][j]; symmetric batches only hold tiles ti >= tj and are mirrored
 template <typename T>
-__global__ void reduce_slabs_kernel(const T* __restrict__ slab, int nsplit, int nbatch, int Mp, int sym, T* __restrict__ out) {
+__global__ void reduce_slabs_kernel(const T* __restrict__ slab, int nsplit, int nbatch, int Mp, int sym, T* __restrict__ out, int QD = GDRF_TILE / 2) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
   if (j >= Mp) return;
-  // sym: 64 x 64 quadrants above the diagonal are mirrored from below (a diagonal tile's upper-right quadrant is not computed
-  // by the bf16 TN kernel; the f32 one computes it, to the same values up to the summation order)
-  constexpr int QD = GDRF_TILE / 2;
+  // sym: QD x QD blocks above the diagonal are mirrored from below (the split TN kernels do not compute them: 64 x 64 quadrants
+  // of diagonal tiles in gemm_tn_split_kernel, 32 x 32 sub-tiles in tn_topics_f16_kernel; the f32 kernel computes them, to the
+  // same values up to the summation order)
   if (sym && (j / QD) > (i / QD)) return;
   const int64_t mm = (int64_t)Mp * Mp;
   double s = 0;

@@ -30,7 +30,7 @@ def headline():
     xs_np, ws_np, _ = synth_circles(N_SIDE, N_SIDE, V, K, seed=777)           # bench.py's workload, same seed
     xs = torch.from_numpy(xs_np).to(dev, torch.float32).contiguous()
     ws = torch.from_numpy(ws_np).to(dev).contiguous()
-    model = SparseMultinomialGDRF(xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=RBF(2, torch.tensor(0.1), torch.tensor(25.0)),
+    model = SparseMultinomialGDRF(xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=RBF(input_dim=2, lengthscale=torch.tensor(0.1), variance=torch.tensor(25.0)),
                                   num_observation_categories=V, num_topic_categories=K, dirichlet_param=0.01, n_points=list(NPTS),
                                   fixed_inducing_points=True, inducing_init="grid", maxjitter=15, jitter=1e-6, device=dev,
                                   dtype=torch.float32, seed=777)
