@@ -55,6 +55,8 @@ struct gdrf_ctx {
   // N-side precision
   void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
+  void *Wd;                   // W' = (dK_nm / d log lengthscale) Linv^T, allocated on first use (fixed inducing inputs, kernels without a third hyper-parameter)
+  double* wdpart; hipEvent_t ev_wd;
   void *Bh, *STh, *Wh;        // 16-bit pieces of B_k, S_k^T and W (f32 contexts; split-operand MFMA forms, gemm_split.h)
   int split;                  // 0: native f32 MFMA; 1: "bf16x6" (3 bf16 pieces, 6 products); 2: "f16x3" (2 fp16 pieces, 3 products, block scales)
   int wh_pieces;              // pieces Wh has room for
@@ -174,6 +176,17 @@ static bool tn_topics_on(const gdrf_ctx* c) {
   const char* e = getenv("GDRF_TN_TOPICS");
   return !(e && e[0] == '0');
 }
+// K_nm parts of the hyper-parameter gradients through W' = (dK/dlog ls) Linv^T (forward-shaped GEMM + two dot products with Wbar)
+// instead of the backward GEMM Kbar = Wbar Linv: fixed inducing inputs (their gradient needs Kbar itself) and kernels whose only
+// shape parameter is the lengthscale
+// Measured at the headline size (profiles/r02): correct, but NOT faster - the step is work-conserving on the matrix pipe, so the second
+// forward-shaped f64 GEMM (6.7 ms alone, 13.8 ms beside fwd_t) costs what the backward GEMM with G^T inside its stalls did (53.0 vs
+// 52.5 ms/step).  Kept as an opt-in (GDRF_WD_PATH=1, covered by a parity test); the backward GEMM is the default.
+static bool wd_path(const gdrf_ctx* c) {
+  if (c->learn_z || c->kind == GDRF_RATIONALQUADRATIC) return false;
+  const char* e = getenv("GDRF_WD_PATH");
+  return e && e[0] == '1';
+}
 static int tn_topics_nsplit(const gdrf_ctx* c, int64_t n) {
   if (const char* e = getenv("GDRF_TNT_NSPLIT")) { const int v = atoi(e); if (v > 0) return v; }
   const int units = tnt_ntiles(c->Mp) * ((c->K + TNT_KT - 1) / TNT_KT);
@@ -209,7 +222,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->split = 0; c->wh_pieces = 0; c->ssc = nullptr; c->smx = nullptr;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0; c->mean = nullptr; c->mean_sk = c->mean_sn = 0;
-  c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr;
+  c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -261,7 +274,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->ssc, (size_t)SplitLay{K}.nfloats() * sizeof(float)) AL(c->smx, (size_t)SplitLay{K}.nmax() * sizeof(unsigned))
 #undef AL
   HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact})
+  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact, &c->ev_wd})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(hipMemset(c->flag, 0, 64));
   HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
@@ -276,7 +289,7 @@ void gdrf_ctx_destroy(gdrf_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& t : c->tev) { (void)hipEventDestroy(t.second.first); (void)hipEventDestroy(t.second.second); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join, c->ev_fact0, c->ev_fact}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join, c->ev_fact0, c->ev_fact, c->ev_wd}) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
@@ -608,9 +621,44 @@ template <typename T, typename TS> struct Impl {
       const int nct_ = (Mp + GDRF_TILE - 1) / GDRF_TILE;
       if (K >= 2 && 2 * grp <= 160 * 1024) {   // two phase-shifted wave groups per workgroup (own A images, shared double-buffered B, LDS-DMA staging)
         const int64_t pairs = (rtiles + 1) / 2;
-        const size_t lds = std::max<size_t>(2 * grp, 8 * 32 * 68 * sizeof(float));      // the epilogue's transposition tiles
-        HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_kernel<SP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((bwd_wbar_split_kernel<SP, 2>), dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds, s, a);
+        const char* alt = getenv("GDRF_WBAR_ALTERNATING");          // A/B knob: the phase-alternating form
+        const size_t tabb = ((size_t)K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15;
+        const size_t lds_cc = 6 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb;
+        if (getenv("GDRF_STAMP_WBAR")) {      // diagnostic: per-phase s_memtime stamps of one workgroup, never in a timed run
+          unsigned long long* d = nullptr;
+          HIPCHK(hipMalloc((void**)&d, 2 * 64 * 4 * 8)); HIPCHK(hipMemset(d, 0, 2 * 64 * 4 * 8));
+          a.stamps = d;
+          HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_cc_kernel<SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_cc + 4096)));
+          hipLaunchKernelGGL((bwd_wbar_split_cc_kernel<SP, true>), dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds_cc + 4096, s, a);
+          std::vector<unsigned long long> h(2 * 64 * 4);
+          HIPCHK(hipStreamSynchronize(s));
+          HIPCHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost)); (void)hipFree(d);
+          for (int gpi = 0; gpi < 2; ++gpi) {
+            double sd = 0, sm = 0, sv = 0, sb = 0; int cnt = 0; std::string line;
+            for (int t = 1; t < 63; ++t) {
+              const unsigned long long* q = &h[(gpi * 64 + t) * 4];
+              const long long dd = q[1] - q[0], m = q[2] - q[1], v = q[3] - q[2], b = h[(gpi * 64 + t + 1) * 4] - q[3];
+              sd += dd; sm += m; sv += v; sb += b; ++cnt;
+              if (t < 24) line += " " + std::to_string(dd) + "/" + std::to_string(m) + "/" + std::to_string(v) + "/" + std::to_string(b);
+            }
+            fprintf(stderr, "wbar_cc stamps group %d: mean dma-issue %.0f mult %.0f vmcnt %.0f barrier %.0f | dma/mult/vmcnt/barrier per phase:%s\n", gpi, sd / cnt,
+                    sm / cnt, sv / cnt, sb / cnt, line.c_str());
+          }
+        } else if (std::is_same<SP, SplitF16>::value && !(alt && alt[0] != '0') && K >= 2 && (Mp % 64) == 0 &&
+                   8 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb <= 160 * 1024) {
+          if constexpr (std::is_same<SP, SplitF16>::value) {
+            const size_t lds64 = 8 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb;
+            HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_f16_k64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+            hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel, dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds64, s, a);
+          }
+        } else if (!(alt && alt[0] == '1') && lds_cc <= 160 * 1024) {
+          HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_cc_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cc));
+          hipLaunchKernelGGL((bwd_wbar_split_cc_kernel<SP>), dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds_cc, s, a);
+        } else {
+          const size_t lds = std::max<size_t>(2 * grp, 8 * 32 * 68 * sizeof(float));      // the epilogue's transposition tiles
+          HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_kernel<SP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL((bwd_wbar_split_kernel<SP, 2>), dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds, s, a);
+        }
       } else {
         if (grp > 160 * 1024) return fail(-1, "wbar_split", "too many topics for the LDS scale table");
         const size_t lds = std::max<size_t>(grp, 4 * 32 * 68 * sizeof(float));
@@ -690,7 +738,7 @@ template <typename T, typename TS> struct Impl {
       if ((rc = knm_solve(c, X, n, s))) return rc;
       if ((rc = join_fact(c, s))) return rc;          // W needs L^-1
       ScopedTimer tm(c, 3, s);
-      FwdWProb<TS, T> p{{}, {}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
+      FwdWProb<TS, T> p{{}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->W), P(c->qpart), ldk};
       if (c->split && sizeof(TS) == 8 && sizeof(T) == 4) {      // pieces of W from the same epilogue
         p.Wh = c->Wh; p.wh_stride = (int64_t)c->ncap * Mp; p.wh_mode = c->split; p.wh_scale = c->ssc + SplitLay{K}.w();
       }
@@ -705,6 +753,31 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, c->side, p);
     }
     HIPCHK(hipEventRecord(c->ev_loc, c->side));
+    // W' = (dK_nm / d log lengthscale) Linv^T on the side stream, beside the K-fold contractions (its f64 MFMAs fill their stalls);
+    // with it the K_nm parts of the hyper-parameter gradients are two dot products with Wbar (wbar_dot_kernel) and the backward
+    // GEMM Kbar = Wbar Linv with its pass over K_nm is not needed
+    const bool use_wd = wd_path(c);
+    if (use_wd) {
+      if (!c->Wd) {
+        void* pw = nullptr;
+        hipError_t e = hipMalloc(&pw, (size_t)c->ncap * Mp * c->esz);
+        if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(Wd)", hipGetErrorString(e));
+        c->Wd = pw; c->allocs.push_back(pw);
+        HIPCHK(hipMalloc(&pw, (size_t)2 * 2048 * sizeof(double))); c->wdpart = (double*)pw; c->allocs.push_back(pw);
+      }
+      ScopedTimer tm(c, 8, c->side);
+      const size_t zl = (size_t)Mp * (c->D <= 2 ? 2 : 4) * sizeof(TS);
+      if (c->D <= 2) {
+        FwdWProb<TS, T, true, 2> p{{}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->Wd), nullptr, 0, X, (const TS*)Q(c->Zs), c->hyp, M, c->D, c->kind};
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TS, FwdWProb<TS, T, true, 2>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CS::LDS_BYTES + zl)));
+        hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T, true, 2>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES + zl, c->side, p);
+      } else {
+        FwdWProb<TS, T, true, 4> p{{}, {}, (const TS*)Q(c->Knm), n, Mp, (const TS*)Q(c->Linv), P(c->Wd), nullptr, 0, X, (const TS*)Q(c->Zs), c->hyp, M, c->D, c->kind};
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_kernel<TS, FwdWProb<TS, T, true, 4>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CS::LDS_BYTES + zl)));
+        hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T, true, 4>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES + zl, c->side, p);
+      }
+      LAUNCHCHK("fwd_wd");
+    }
     // (2) tt_kn = ||S_k^T w_n||^2
     if (c->split) {
       if ((rc = (c->split == 2 ? fwd_t_split<SplitF16>(c, n, rtiles, s) : fwd_t_split<SplitBf16>(c, n, rtiles, s)))) return rc;
@@ -803,8 +876,15 @@ template <typename T, typename TS> struct Impl {
                          redT + roff(c, 0));
     }
     HIPCHK(hipEventRecord(c->ev_join, c->side));
-    // (4) kernel hyper-parameter partials through Knm (solve precision)
-    {
+    // (4) kernel hyper-parameter partials through K_nm
+    if (use_wd) {
+      // on the side stream, behind W' and G^T / ubar: sum Wbar o W -> red_d[4], sum Wbar o W' -> red_d[5]; red_d[6] = 0
+      hipStream_t ss = c->side;
+      hipLaunchKernelGGL(wbar_dot_kernel<T>, dim3(2048), dim3(256), 0, ss, (const T*)P(c->Wbar), (const T*)P(c->W), (const T*)P(c->Wd), n, Mp, c->wdpart);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, ss, c->wdpart, (int64_t)2048, 2, redd + 4);
+      HIPCHK(hipMemsetAsync(redd + 6, 0, sizeof(double), ss));
+      HIPCHK(hipEventRecord(c->ev_join, c->side));           // the join event now also covers these
+    } else {
       ScopedTimer tm(c, 8, s);
       const int64_t nb = nt_xcd_row_grid(rtiles, nct<TS>(c));
       if (3 * nb > c->dpart_len) return fail(-1, "gdrf_step_local", "n_local exceeds the context capacity");

@@ -18,7 +18,7 @@
 //   int  extra_lds_bytes()                problem-owned LDS behind the two staging tiles
 //   void krange(m0, n0, bz, kb, ke)       A-column range [kb, ke), multiples of BK (triangular skipping)
 //   void prepA(actx, m0, bz, extra) ; AVec loadA(actx, i, k, bz)  i = 0..VPT-1: the thread's i-th staged row
-//   V    a_to_lds(AVec)                   conversion applied when the prefetched registers are written to LDS (so that a
+//   V    a_to_lds(AVec, actx, i, k)       conversion applied when the prefetched registers are written to LDS (so that a
 //                                         precision change does not force a wait on the loads ahead of the MFMAs)
 //   V    loadB(n0, i, k, rep, bz)
 //   int  extra_chunks(); void fill_extra(As, Bs, x, m0, n0)   problem-staged chunks multiplied after the main reduction
@@ -161,7 +161,7 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
       __syncthreads();
       if (rep == 0 || P::A_PER_REP) {
 #pragma unroll
-        for (int i = 0; i < C::VPT; ++i) *reinterpret_cast<V*>(&As[nt_stage_row<T>(i) * C::LDK + srow_k]) = p.a_to_lds(ra[i]);
+        for (int i = 0; i < C::VPT; ++i) *reinterpret_cast<V*>(&As[nt_stage_row<T>(i) * C::LDK + srow_k]) = p.a_to_lds(ra[i], actx, i, kA + srow_k);
       }
 #pragma unroll
       for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
@@ -205,7 +205,7 @@ template <typename T> __device__ __forceinline__ int nt_acc_col(int wc, int b, i
 // default staging: the prefetched A registers already hold the LDS representation
 template <typename T> struct NTPlainA {
   using AVec = typename Vec16<T>::type;
-  __device__ __forceinline__ AVec a_to_lds(const AVec& v) const { return v; }
+  template <class... X> __device__ __forceinline__ AVec a_to_lds(const AVec& v, X&&...) const { return v; }
 };
 // default: no problem-owned extra chunks
 struct NTNoExtra {

@@ -143,12 +143,18 @@ __device__ __forceinline__ int split_off(int row, int k) { return row * 32 + (((
 // next LDS read of the issuing wave (a builtin glds is a pending LDS write to the compiler, so every ds_read behind it waits for it:
 // the "prefetch" of the next chunk was retired BEFORE the current chunk's MFMAs).  The caller orders it by hand: it is older than
 // any register load issued after it, vmcnt retires in order, so the wait hipcc puts in front of the first use of such a load also
-// covers it; a barrier then publishes it to the other waves.  M0 is written in the statement that reads it and restored
+// covers it; a barrier then publishes it to the other waves.  M0 is written in the statement that reads it
 // (cdna_hip_programming.md 5.7).  lds_dst: wave-uniform LDS byte address; gsrc: this lane's 16 source bytes.
 __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  // M0 is not restored: a write to M0 directly behind the DMA waits until the DMA has consumed it - measured ~100-200 cycles of wave
+  // stall per request.  Nothing else in these kernels uses M0 (no builtin LDS-DMA, no s_movrel / sendmsg; DS instructions do not need
+  // it on gfx9+), and every statement that needs it sets it itself.
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned long long split_stamp() {          // diagnostic builds only
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -208,6 +214,7 @@ template <class SP> struct BwdWbarSplitArgs {
   const float* asum; const float* U; float* Wbar;
   const float* sc;                             // block scales (SplitLay)
   unsigned* wbar_max;                          // max |Wbar| (bits), for the scale of the G^T contraction's operand
+  unsigned long long* stamps = nullptr;        // diagnostic builds only (STAMP)
 };
 
 // NG = 1: one 256-thread workgroup per tile, two workgroups per CU (they share the CU's SIMDs at random).
@@ -499,6 +506,394 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_split_kernel(BwdWbarSpli
   }
 }
 
+// bwd_wbar with BOTH wave groups multiplying in every phase (see fwd_t_split_cc_kernel): one phase = one (reduction block q,
+// topic rep) chunk for all 8 waves; the next chunk's B image (shared, double-buffered) and - when the next chunk opens a new
+// reduction block - the groups' next A images (double-buffered) are requested by asm LDS-DMA at the top of the phase and retired
+// by the vmcnt(0) in front of the barrier that ends it.
+template <class SP, bool STAMP = false>
+__global__ __launch_bounds__(512, 2) void bwd_wbar_split_cc_kernel(BwdWbarSplitArgs<SP> g) {
+  using CF = SplitCfg<SP>;
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  constexpr int NP = SP::NP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  constexpr int IMG = CF::IMG;
+  const size_t tab = ((size_t)g.K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15;
+  E* As = reinterpret_cast<E*>(smem) + gp * 2 * IMG;                     // [2 buffers][NP][128][LDH] of this group
+  E* Bs = reinterpret_cast<E*>(smem) + 4 * IMG;                          // [2 buffers][NP][128][LDH] shared
+  float* scaleS = reinterpret_cast<float*>(smem + (size_t)6 * IMG * 2 + (size_t)gp * tab);  // [K][128]  2 vbar_kn / (sW sB_k)
+
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  const int nct = (g.Mp + GDRF_TILE - 1) / GDRF_TILE;
+  int64_t rtile; int ct;
+  {
+    const unsigned w = blockIdx.x;
+    if (nct <= 8 && (8 % nct) == 0 && (gridDim.x % 8u) == 0) {
+      const unsigned xcd = w & 7u, idx = w >> 3, per = 8u / (unsigned)nct;
+      ct = (int)(xcd % (unsigned)nct);
+      rtile = 2 * ((int64_t)idx * per + xcd / (unsigned)nct) + gp;
+    } else {
+      ct = (int)(w % (unsigned)nct);
+      rtile = 2 * (int64_t)(w / (unsigned)nct) + gp;
+    }
+  }
+  const int64_t m0 = rtile * GDRF_TILE;
+  const int n0 = ct * GDRF_TILE;
+  const int K = g.K, Mp = g.Mp;
+  const SplitLay SL{K};
+  {
+    const float unw = g.sc[SL.w() + 1];
+    for (int e = tid; e < K * GDRF_TILE; e += 256) {
+      const int k = e / GDRF_TILE, r = e - k * GDRF_TILE;
+      scaleS[e] = (m0 + r < g.nrows) ? 2.0f * g.vbar[(int64_t)k * g.ldk + m0 + r] * (unw * g.sc[SL.b(k) + 1]) : 0.0f;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  V8 fa[4][NP];
+  const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);
+  const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned a_lds = lds_addr(As), b_lds = lds_addr(Bs);
+  const int nk = Mp / CF::BK, nchunks = nk * K;
+  // One LDS-DMA instruction costs its wave ~190 cycles of issue here (s_memtime: 380 cycles for two, in front of the MFMAs, with the
+  // other wave of the SIMD not yet multiplying either): the requests of a phase are therefore issued one at a time BETWEEN the
+  // MFMA groups of the phase, where the stall of the issuing wave is covered by MFMAs already in the pipe and by its partner's.
+  const int b_rbk = wave_u + 4 * gp, b_row = b_rbk * 16 + drow;
+  const int b_col = (n0 + b_row < Mp) ? n0 + b_row : 0;
+  auto dma_b1 = [&](int c, int p) {       // piece p of B chunk c -> buffer c & 1: this wave (of 8) moves one 16-row block
+    const int q = c / K, rep = c - q * K;
+    glds16_asm(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + q) * Mp + b_col) * 32 + dq,
+               b_lds + (unsigned)((((c & 1) * NP + p) * CF::PIECE + b_rbk * 512) * 2));
+  };
+  auto dma_a1 = [&](int q, int i, int p) { // piece p, row block wave + 4 i of this group's A image of reduction block q -> buffer q & 1
+    const int rbk = wave_u + 4 * i;
+    int64_t row = m0 + rbk * 16 + drow;
+    row = row < g.nrows ? row : 0;
+    glds16_asm(g.Wh + p * g.w_stride + row * Mp + q * CF::BK + dq, a_lds + (unsigned)((((q & 1) * NP + p) * CF::PIECE + rbk * 512) * 2));
+  };
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { dma_a1(0, 0, p); dma_a1(0, 1, p); dma_b1(0, p); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                        // also publishes the scale table
+  const bool stamping = STAMP && blockIdx.x == 6000 && (wave == 0) && lane == 0;
+  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(smem + (size_t)6 * IMG * 2 + 2 * tab);   // [2][64][4]
+  auto stamp = [&](int c, int i) {
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); if (stamping && c >= 20 && c < 84) lstamp[(gp * 64 + c - 20) * 4 + i] = split_stamp(); __builtin_amdgcn_sched_barrier(0); }
+  };
+  for (int c = 0; c < nchunks; ++c) {
+    const int q = c / K, rep = c - q * K;
+    stamp(c, 0);
+    const bool more = c + 1 < nchunks, more_a = more && rep == K - 1;
+    stamp(c, 1);
+    const E* Ab = As + (q & 1) * IMG;
+    const E* Bb = Bs + (c & 1) * IMG;
+    if (rep == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) fa[a][p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
+    }
+    const float* sc_row = scaleS + rep * GDRF_TILE;
+    f32x4 s4[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s4[a] = *reinterpret_cast<const f32x4*>(sc_row + wr * 64 + a * 16 + lg * 4);
+    V8 fbq[2][NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fbq[0][p] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64) * 32 + frag);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      V8 (&fb)[NP] = fbq[b & 1];
+      if (b + 1 < 4) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) fbq[(b + 1) & 1][p] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + (b + 1) * 16) * 32 + frag);
+      }
+      f32x4 P[4];
+#pragma unroll
+      for (int t = 0; t < SP::NPROD; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) P[a] = SP::mma(fa[a][SP::pa(t)], fb[SP::pb(t)], t == 0 ? f32x4{0, 0, 0, 0} : P[a]);
+      // the next chunk's requests, behind this column group's MFMAs: B (buffer (c + 1) & 1, last read one phase ago) after groups
+      // 0 .. NP - 1; when the next chunk opens a reduction block, the group's next A image (last read K phases ago) after them
+      if (more && b < NP) dma_b1(c + 1, b);
+      if (more_a) {
+        if (NP == 2) { dma_a1(q + 1, b >> 1, b & 1); }
+        else if (b < 3) { dma_a1(q + 1, 0, b); dma_a1(q + 1, 1, b); }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += s4[a][r] * P[a][r];
+    }
+    stamp(c, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(c, 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (STAMP) { if (stamping) for (int i = 0; i < 64 * 4; ++i) g.stamps[gp * 256 + i] = lstamp[gp * 256 + i]; }
+  // rank-K epilogue term locbar^T U on the native f32 matrix instruction (exact f32, no split, no range question): lane
+  // (lr, lg) supplies A[row lr][k = lg] and B[k = lg][col lr] of v_mfma_f32_16x16x4_f32, whose C/D layout is the accumulators'
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + lg;
+    float av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t row = m0 + wr * 64 + a * 16 + lr;
+      av[a] = (k < K && row < g.nrows) ? g.locbar[(int64_t)k * g.ldk + row] : 0.0f;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = n0 + wc * 64 + b * 16 + lr;
+      bv[b] = (k < K && col < g.M) ? g.U[(int64_t)k * g.M + col] : 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+  // Wbar = acc - 2 asum W.  The MFMA accumulator layout (a lane owns one column of four rows) would make this 64 scalar
+  // loads of W and 64 scalar stores per lane in a dependent sequence - measured ~300k cycles per workgroup, a third of its
+  // lifetime.  Instead each wave transposes its 64 x 64 quadrant through a private LDS tile, 32 rows at a time, and moves whole
+  // 256-byte row segments: 16 float4 loads and 16 float4 stores per lane.
+  __syncthreads();                                           // every wave is done with the operand images
+  float wmax = 0.0f;
+  {
+    constexpr int TS = 68;                                   // tile row stride in floats (272 B: 16-byte aligned, bank-shifted)
+    float* tile = reinterpret_cast<float*>(smem) + (size_t)(gp * 4 + wave) * (32 * TS);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[(a2 * 16 + lg * 4 + r) * TS + b * 16 + lr] = acc[2 * h + a2][b][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave writes and reads: LDS is in order per wave
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = (lane >> 4) + 4 * i, cv = (lane & 15) * 4;
+        const int64_t m = m0 + wr * 64 + h * 32 + rr;
+        const int n = n0 + wc * 64 + cv;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + rr * TS + cv);
+        if (m < g.nrows && n < Mp) {                         // Mp is a multiple of 32: a float4 never straddles the edge
+          const float as2 = 2.0f * g.asum[m];
+          const f32x4 w = *reinterpret_cast<const f32x4*>(g.W + m * Mp + n);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = t[e] - as2 * w[e]; wmax = fmaxf(wmax, fabsf(o[e])); }
+          *reinterpret_cast<f32x4*>(g.Wbar + m * Mp + n) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the tile is overwritten with the other half
+    }
+  }
+  if (g.wbar_max) {                                          // order-independent: the maximum of non-negative floats as integers
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0 && wmax > 0.0f) atomicMax(g.wbar_max, __float_as_uint(wmax));
+  }
+}
+
+
+// bwd_wbar, concurrent form, 64 reduction indices per phase (f16x3 only).  Stamps of the 32-deep form: a phase is ~2650 cycles for
+// 2 x 768 cycles of MFMA per SIMD; what fills it is ISSUE - per wave 48 MFMAs (8 issue cycles each) plus ~100 vector instructions of
+// which 64 are the acc += s P update that the per-(topic, row) factor forces after every chunk - not the matrix pipe.  Two 32-deep
+// k-steps per (reduction block, topic) halve that update per MFMA: 96 MFMAs, one update, one barrier per phase.  LDS: the A image
+// (this group's rows x 64 k, 32 KB) is SINGLE-buffered - its fragments live in registers for the K topic phases of a block, so the
+// next block's image is requested in the phase after they were read (K >= 2) -; B (shared, 32 KB) is double-buffered.
+__global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitArgs<SplitF16> g) {
+  using SP = SplitF16;
+  using CF = SplitCfg<SP>;
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  constexpr int NP = SP::NP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  constexpr int IMG = CF::IMG;                                            // one 32-deep image: [NP][128][32]
+  const size_t tab = ((size_t)g.K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15;
+  E* As = reinterpret_cast<E*>(smem) + gp * 2 * IMG;                     // [2 k-steps][NP][128][32] of this group
+  E* Bs = reinterpret_cast<E*>(smem) + 4 * IMG;                          // [2 buffers][2 k-steps][NP][128][32] shared
+  float* scaleS = reinterpret_cast<float*>(smem + (size_t)8 * IMG * 2 + (size_t)gp * tab);
+
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  const int nct = (g.Mp + GDRF_TILE - 1) / GDRF_TILE;
+  int64_t rtile; int ct;
+  {
+    const unsigned w = blockIdx.x;
+    if (nct <= 8 && (8 % nct) == 0 && (gridDim.x % 8u) == 0) {
+      const unsigned xcd = w & 7u, idx = w >> 3, per = 8u / (unsigned)nct;
+      ct = (int)(xcd % (unsigned)nct);
+      rtile = 2 * ((int64_t)idx * per + xcd / (unsigned)nct) + gp;
+    } else {
+      ct = (int)(w % (unsigned)nct);
+      rtile = 2 * (int64_t)(w / (unsigned)nct) + gp;
+    }
+  }
+  const int64_t m0 = rtile * GDRF_TILE;
+  const int n0 = ct * GDRF_TILE;
+  const int K = g.K, Mp = g.Mp;
+  const SplitLay SL{K};
+  {
+    const float unw = g.sc[SL.w() + 1];
+    for (int e = tid; e < K * GDRF_TILE; e += 256) {
+      const int k = e / GDRF_TILE, r = e - k * GDRF_TILE;
+      scaleS[e] = (m0 + r < g.nrows) ? 2.0f * g.vbar[(int64_t)k * g.ldk + m0 + r] * (unw * g.sc[SL.b(k) + 1]) : 0.0f;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  V8 fa[2][4][NP];
+  const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);
+  const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned a_lds = lds_addr(As), b_lds = lds_addr(Bs);
+  const int nk = Mp / 64, nchunks = nk * K;                              // Mp % 64 == 0 (checked by the host)
+  const int b_rbk = wave_u + 4 * gp, b_row = b_rbk * 16 + drow;
+  const int b_col = (n0 + b_row < Mp) ? n0 + b_row : 0;
+  // B chunk c = (block q, topic rep), k-step ks, piece p -> buffer c & 1: this wave (of 8) moves one 16-row block
+  auto dma_b1 = [&](int c, int ks, int p) {
+    const int q = c / K, rep = c - q * K;
+    glds16_asm(g.Bh + p * g.piece_stride + (((int64_t)rep * (Mp >> 5) + 2 * q + ks) * Mp + b_col) * 32 + dq,
+               b_lds + (unsigned)(((((c & 1) * 2 + ks) * NP + p) * CF::PIECE + b_rbk * 512) * 2));
+  };
+  // this group's A image of block q: k-step ks, piece p, row block wave + 4 i
+  auto dma_a1 = [&](int q, int ks, int i, int p) {
+    const int rbk = wave_u + 4 * i;
+    int64_t row = m0 + rbk * 16 + drow;
+    row = row < g.nrows ? row : 0;
+    glds16_asm(g.Wh + p * g.w_stride + row * Mp + q * 64 + ks * 32 + dq, a_lds + (unsigned)(((ks * NP + p) * CF::PIECE + rbk * 512) * 2));
+  };
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { dma_a1(0, ks, 0, p); dma_a1(0, ks, 1, p); dma_b1(0, ks, p); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                        // also publishes the scale table
+  for (int c = 0; c < nchunks; ++c) {
+    const int q = c / K, rep = c - q * K;
+    const bool more = c + 1 < nchunks, more_a = rep == 1 && q + 1 < nk;   // A(q + 1) into the image whose fragments were read one phase ago
+    const E* Bb = Bs + (c & 1) * 2 * IMG;
+    if (rep == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) fa[ks][a][p] = *reinterpret_cast<const V8*>(As + (ks * NP + p) * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
+    }
+    const float* sc_row = scaleS + rep * GDRF_TILE;
+    f32x4 s4[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s4[a] = *reinterpret_cast<const f32x4*>(sc_row + wr * 64 + a * 16 + lg * 4);
+    V8 fbq[2][2][NP];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) fbq[0][ks][p] = *reinterpret_cast<const V8*>(Bb + (ks * NP + p) * CF::PIECE + (wc * 64) * 32 + frag);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      V8 (&fb)[2][NP] = fbq[b & 1];
+      if (b + 1 < 4) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            fbq[(b + 1) & 1][ks][p] = *reinterpret_cast<const V8*>(Bb + (ks * NP + p) * CF::PIECE + (wc * 64 + (b + 1) * 16) * 32 + frag);
+      }
+      f32x4 P[4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < SP::NPROD; ++t)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) P[a] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], (ks == 0 && t == 0) ? f32x4{0, 0, 0, 0} : P[a]);
+      // the next chunk's requests, one or two behind each column group's MFMAs (an LDS-DMA instruction stalls its wave at issue)
+      if (more) dma_b1(c + 1, b >> 1, b & 1);
+      if (more_a) { dma_a1(q + 1, b >> 1, 0, b & 1); dma_a1(q + 1, b >> 1, 1, b & 1); }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += s4[a][r] * P[a][r];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // rank-K epilogue term locbar^T U on the native f32 matrix instruction (exact f32, no split, no range question): lane
+  // (lr, lg) supplies A[row lr][k = lg] and B[k = lg][col lr] of v_mfma_f32_16x16x4_f32, whose C/D layout is the accumulators'
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + lg;
+    float av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t row = m0 + wr * 64 + a * 16 + lr;
+      av[a] = (k < K && row < g.nrows) ? g.locbar[(int64_t)k * g.ldk + row] : 0.0f;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = n0 + wc * 64 + b * 16 + lr;
+      bv[b] = (k < K && col < g.M) ? g.U[(int64_t)k * g.M + col] : 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+  // Wbar = acc - 2 asum W.  The MFMA accumulator layout (a lane owns one column of four rows) would make this 64 scalar
+  // loads of W and 64 scalar stores per lane in a dependent sequence - measured ~300k cycles per workgroup, a third of its
+  // lifetime.  Instead each wave transposes its 64 x 64 quadrant through a private LDS tile, 32 rows at a time, and moves whole
+  // 256-byte row segments: 16 float4 loads and 16 float4 stores per lane.
+  __syncthreads();                                           // every wave is done with the operand images
+  float wmax = 0.0f;
+  {
+    constexpr int TS = 68;                                   // tile row stride in floats (272 B: 16-byte aligned, bank-shifted)
+    float* tile = reinterpret_cast<float*>(smem) + (size_t)(gp * 4 + wave) * (32 * TS);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[(a2 * 16 + lg * 4 + r) * TS + b * 16 + lr] = acc[2 * h + a2][b][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave writes and reads: LDS is in order per wave
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = (lane >> 4) + 4 * i, cv = (lane & 15) * 4;
+        const int64_t m = m0 + wr * 64 + h * 32 + rr;
+        const int n = n0 + wc * 64 + cv;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + rr * TS + cv);
+        if (m < g.nrows && n < Mp) {                         // Mp is a multiple of 32: a float4 never straddles the edge
+          const float as2 = 2.0f * g.asum[m];
+          const f32x4 w = *reinterpret_cast<const f32x4*>(g.W + m * Mp + n);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = t[e] - as2 * w[e]; wmax = fmaxf(wmax, fabsf(o[e])); }
+          *reinterpret_cast<f32x4*>(g.Wbar + m * Mp + n) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the tile is overwritten with the other half
+    }
+  }
+  if (g.wbar_max) {                                          // order-independent: the maximum of non-negative floats as integers
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0 && wmax > 0.0f) atomicMax(g.wbar_max, __float_as_uint(wmax));
+  }
+}
+
+
+
 // ------------------------------------------------------------------------------------------------------------------
 // tt[k][n] = || S_k^T w_n ||^2 on the same emulation: T_k = W S_k lives only in the accumulators; a row tile and topic walk
 // the column tiles (triangular k range i >= j), as gemm_nt<FwdTProb> does.
@@ -510,11 +905,7 @@ template <class SP> struct FwdTSplitArgs {
   const float* sc;
   unsigned long long* stamps;                 // diagnostic builds only (template parameter STAMP): [2 groups][phases][4] s_memtime values of one workgroup
 };
-__device__ __forceinline__ unsigned long long split_stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-  return t;
-}
+
 
 // tt in the two-group LDS-DMA structure of bwd_wbar_split_kernel<2>: a 512-thread workgroup holds two adjacent row tiles of
 // one topic, one per wave group; both walk the same (column tile, reduction chunk) sequence, so the S_k^T chunk is staged once
@@ -734,24 +1125,26 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned a_lds = lds_addr(As), b_lds = lds_addr(Bs);
   // chunk (ct, kA) -> buffer buf: A rows of this group (2 row blocks per wave), B columns (1 row block per wave of the 8)
-  auto dma = [&](int ct, int kA, int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+  // the requests of a chunk, one at a time (see bwd_wbar_split_cc_kernel: an LDS-DMA instruction stalls its wave ~190 cycles at issue,
+  // which the MFMAs around it cover): slot 0 .. 2 NP - 1 = this group's A rows (2 row blocks per wave), 2 NP .. 3 NP - 1 = the B columns
+  auto dma1 = [&](int ct, int kA, int buf, int slot) {
+    if (slot < 2 * NP) {
+      const int i = slot / NP, p = slot - i * NP;
       const int rbk = wave_u + 4 * i;
       int64_t row = m0 + rbk * 16 + drow;
       row = row < g.nrows ? row : 0;
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        glds16_asm(g.Wh + p * g.w_stride + row * Mp + kA + dq, a_lds + (unsigned)(((buf * NP + p) * CF::PIECE + rbk * 512) * 2));
-    }
-    {
+      glds16_asm(g.Wh + p * g.w_stride + row * Mp + kA + dq, a_lds + (unsigned)(((buf * NP + p) * CF::PIECE + rbk * 512) * 2));
+    } else {
+      const int p = slot - 2 * NP;
       const int rbk = wave_u + 4 * gp, row = rbk * 16 + drow;
       const int col = (ct * GDRF_TILE + row < Mp) ? ct * GDRF_TILE + row : 0;
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        glds16_asm(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + dq,
-                   b_lds + (unsigned)(((buf * NP + p) * CF::PIECE + rbk * 512) * 2));
+      glds16_asm(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + col) * 32 + dq,
+                 b_lds + (unsigned)(((buf * NP + p) * CF::PIECE + rbk * 512) * 2));
     }
+  };
+  auto dma = [&](int ct, int kA, int buf) {
+#pragma unroll
+    for (int sl = 0; sl < 3 * NP; ++sl) dma1(ct, kA, buf, sl);
   };
   float rs[4][4];
 #pragma unroll
@@ -774,7 +1167,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
     int ct1 = ct, kA1 = kA + CF::BK;
     const bool last = kA1 >= Mp;
     if (last) { ct1 = ct + 1; kA1 = ct1 * GDRF_TILE; }
-    if (ct1 < nct) dma(ct1, kA1, buf ^ 1);                    // buffers buf ^ 1 were last read one phase ago
+    const bool more = ct1 < nct;                               // buffers buf ^ 1 were last read one phase ago
     const E* Ab = As + buf * IMG;
     const E* Bb = Bs + buf * IMG;
     V8 fb[NP][4];
@@ -796,6 +1189,11 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
       for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = SP::mma(fa[SP::pa(t)], fb[SP::pb(t)][b], acc[a][b]);
+      if (more) {                                               // the next chunk's requests, spread behind the MFMA groups
+        constexpr int NS = 3 * NP, PER = (NS + 2) / 3;          // over a = 0, 1, 2
+#pragma unroll
+        for (int sl = a * PER; sl < (a + 1) * PER && sl < NS; ++sl) if (a < 3) dma1(ct1, kA1, buf ^ 1, sl);
+      }
     }
     if (last) {                                                 // fold the finished column tile into the row sums, restart the accumulators
 #pragma unroll

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
   // split x (4 columns of this lane's row) for the topic pair pr of chunk c into B image buffer q
   auto split_pair = [&](const f32x4& x, int c, int pr, int q) {
     const float* vt = vtab + ((c & 1) * KT + 2 * pr) * 32 + brow;
-    const float v0 = b_ok ? vt[0] : 0.0f, v1 = b_ok ? vt[32] : 0.0f;      // 2 pr + 1 < KT always (KT even)
+    const float okf = b_ok ? 1.0f : 0.0f;
+    const float v0 = vt[0] * okf, v1 = vt[32] * okf;                      // 2 pr + 1 < KT always (KT even); unconditional LDS reads
     V4 pv[2][NP];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
               if (npair == 1) phase_barrier(); // the factors are used by the split below in this same phase when there is only one pair
             }
           }
-          // produce the next B image while this one is multiplied
+          // produce the next B image while this one is multiplied (all four fragments of the pair up front cost 16 registers more
+          // than the 256 a two-waves-per-SIMD kernel has: spills, 10.1 -> 11.0 ms)
           if (pr + 1 < npair) split_pair(rb, c, pr + 1, q ^ 1);
           else if (more) split_pair(rbn, c + 1, 0, q ^ 1);
           if (active) {

@@ -162,16 +162,22 @@ template <> __device__ __forceinline__ float cov_fast<float>(int kind, float r2,
 //     stores W and the per-column-tile partial of q_n = ||w_n||^2.
 // T = solve precision (f64 in the default fp32 mode: the triangular solve cancels terms ~|Linv||k| >> |w|),
 // TN = precision of the N-sized outputs (W, qpart)
-template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, NTNoExtra {
+// DERIV: the A operand is dK_nm / d log(lengthscale) instead of K_nm, formed from the K_nm chunk when it is written to LDS
+// (dcov_dlogls_from_k: no second exponential); the product W' = K' Linv^T gives the K_nm part of the lengthscale gradient as
+// sum W' o Wbar, and sum W o Wbar is the variance part (Kbar = Wbar Linv, so sum_m Kbar_nm K_nm = sum_j Wbar_nj W_nj): no
+// backward GEMM, no second pass over K_nm.  Z (solve precision, [M][D]) sits in the problem-owned LDS behind the tiles.
+template <typename T, typename TN, bool DERIV = false, int DD = 2> struct FwdWProb : NTXcdRowMap, NTNoExtra {
   using V = typename Vec16<T>::type;
+  using AVec = V;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
   static constexpr int DEPTH = 1;
   const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
+  const TN* X = nullptr; const T* Z = nullptr; const Hyper* h = nullptr; int M = 0, D = 0, kind = 0;   // DERIV only
   void* Wh = nullptr; int64_t wh_stride = 0;          // optional: the 16-bit pieces of W (gemm_split.h), written by the same epilogue
   int wh_mode = 0; const float* wh_scale = nullptr;   // 1: three bf16 pieces; 2: two fp16 pieces of W * wh_scale[0]
-  struct ACtx { const T* p[NTCfg<T>::VPT]; };
+  struct ACtx { const T* p[NTCfg<T>::VPT]; T x[DERIV ? NTCfg<T>::VPT : 1][DD]; const T* zS; T ils2, al; };
   struct ECtx { T rs[4][4]; int ct; };
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
@@ -179,11 +185,35 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
   __device__ __forceinline__ void krange(int64_t, int n0, int, int& kb, int& ke) const {
     kb = 0; ke = n0 + NTCfg<T>::CW; if (ke > Mp) ke = Mp;
   }
-  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const {
+  __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char* extra) const {
 #pragma unroll
     for (int i = 0; i < NTCfg<T>::VPT; ++i) {
       const int64_t r = m0 + nt_stage_row<T>(i);
       c.p[i] = (r < nrows) ? Knm + r * Mp : nullptr;
+      if constexpr (DERIV) {
+#pragma unroll
+        for (int d = 0; d < DD; ++d) c.x[i][d] = (r < nrows && d < D) ? (T)X[r * D + d] : T(0);
+      }
+    }
+    if constexpr (DERIV) {
+      T* zs = reinterpret_cast<T*>(extra);                  // [Mp][DD], zero beyond (M, D)
+      for (int e = threadIdx.x; e < Mp * DD; e += 256) { const int m = e / DD, d = e - m * DD; zs[e] = (m < M && d < D) ? Z[m * D + d] : T(0); }
+      c.zS = zs; c.ils2 = (T)h->inv_ls2; c.al = (T)h->alpha;
+      __syncthreads();
+    }
+  }
+  __device__ __forceinline__ V a_to_lds(const V& v, const ACtx& c, int i, int k) const {
+    if constexpr (!DERIV) return v;
+    else {
+      V o;
+#pragma unroll
+      for (int e = 0; e < Vec16<T>::N; ++e) {
+        T r2 = 0;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) { const T t = c.x[i][d] - c.zS[(k + e) * DD + d]; r2 += t * t; }
+        o[e] = dcov_dlogls_from_k<T>(kind, v[e], r2 * c.ils2, c.al);
+      }
+      return o;
     }
   }
   __device__ __forceinline__ void prepE(ECtx& e, int64_t, int) const {
@@ -210,8 +240,8 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
 #pragma unroll
         for (int b = 0; b < NTCfg<T>::NB; ++b) ec.rs[a][r] += acc[a][b][r] * acc[a][b][r];
     if constexpr (sizeof(T) == 8 && sizeof(TN) == 4) {
-      if (Wh) {
-        // f64 solve, f32 W, bf16x6 contractions: each wave transposes its 64 x 32 quadrant through a private LDS tile, 32 rows
+      {
+        // f64 solve, f32 W, split contractions: each wave transposes its 64 x 32 quadrant through a private LDS tile, 32 rows
         // at a time, and stores whole 128-byte row segments - W as float4 and its three bf16 pieces as 8-byte vectors - instead
         // of 32 scalar stores per lane followed by a separate pass that re-reads all of W to split it.
         extern __shared__ __attribute__((aligned(16))) char nt_smem[];
@@ -239,6 +269,7 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
             if (m < nrows && n < Mp) {                        // Mp is a multiple of 32: a vector never straddles the edge
               *reinterpret_cast<f4*>(W + m * Mp + n) = t;
               auto put = [&](auto sp) {
+                if (!Wh) return;
                 using SP = decltype(sp);
                 typename SP::V4 pv[SP::NP];
 #pragma unroll
@@ -273,6 +304,7 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
       }
   }
   __device__ __forceinline__ void finish(int64_t m0, int, ECtx& ec, char* smem, int wr, int wc, int lane) const {
+    if (!qpart) return;                                     // the derivative product has no row norms to report
     T* rsum = reinterpret_cast<T*>(smem);
     nt_rowsum_finish<T>(ec.rs, rsum, wr, wc, lane);
     if (threadIdx.x < GDRF_TILE) {
@@ -281,6 +313,27 @@ template <typename T, typename TN> struct FwdWProb : NTXcdRowMap, NTPlainA<T>, N
     }
   }
 };
+
+// sum_n,j Wbar[n][j] W[n][j] and sum Wbar[n][j] Wd[n][j] (per-workgroup partials [grid][2], deterministic order): the K_nm parts of the
+// variance / lengthscale gradients when W' = (dK_nm / d log ls) Linv^T is available (FwdWProb<.., DERIV>)
+template <typename T>
+__global__ __launch_bounds__(256) void wbar_dot_kernel(const T* __restrict__ Wbar, const T* __restrict__ W, const T* __restrict__ Wd, int64_t nrows,
+                                                       int Mp, double* __restrict__ part) {
+  using V = typename Vec16<T>::type;
+  constexpr int VE = Vec16<T>::N;
+  __shared__ double scratch[16];
+  const int64_t nvec = nrows * Mp / VE;                     // Mp is a multiple of 32; padded columns hold zeros
+  double s1 = 0, s2 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const V b = reinterpret_cast<const V*>(Wbar)[i], w = reinterpret_cast<const V*>(W)[i], d = reinterpret_cast<const V*>(Wd)[i];
+    T a1 = 0, a2 = 0;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { a1 += b[e] * w[e]; a2 += b[e] * d[e]; }
+    s1 += (double)a1; s2 += (double)a2;
+  }
+  const double t1 = block_sum(s1, scratch), t2 = block_sum(s2, scratch);
+  if (threadIdx.x == 0) { part[2 * (int64_t)blockIdx.x] = t1; part[2 * (int64_t)blockIdx.x + 1] = t2; }
+}
 
 // (1b) loc = W U^T on the matrix cores: Bt = zero-padded u_loc [128][Mp]; stores loc[k][n] for k < K
 template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
@@ -595,7 +648,7 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
     if (c.p[i]) t = *reinterpret_cast<const AVec*>(c.p[i] + k);
     return t;
   }
-  __device__ __forceinline__ V a_to_lds(const AVec& t) const {
+  template <class... X> __device__ __forceinline__ V a_to_lds(const AVec& t, X&&...) const {
     V v;
 #pragma unroll
     for (int e = 0; e < Vec16<T>::N; ++e) v[e] = (T)t[e];

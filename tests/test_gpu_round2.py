@@ -165,3 +165,19 @@ def test_packed_payload_sums_like_float64(dtype):
     scale = torch.stack(vals).abs().max(0).values
     err = ((eng.red_d - ref).abs() / scale).max().item()
     assert err < (1e-15 if dtype == torch.float64 else 1e-12), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+def test_hyper_gradients_through_the_derivative_product(dtype, kind, monkeypatch):
+    """GDRF_WD_PATH=1: the K_nm parts of the lengthscale / variance gradients as sum Wbar o W' and sum Wbar o W with
+    W' = (dK_nm / d log ls) Linv^T (a second forward-shaped GEMM) instead of the backward GEMM Kbar = Wbar Linv."""
+    monkeypatch.setenv("GDRF_WD_PATH", "1")
+    m, eps = make_oracle(dtype=torch.float64, jitter=1e-4, kind=kind, W=23, H=11, V=7, K=3, n_points=(6, 6), lengthscale=0.15)
+    loss, grads = m.loss_and_grads(eps)
+    eng = engine_from_oracle(m, dtype=dtype)
+    eng.loss_and_grads(dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=m.last_jitter_level)
+    tol = 1e-8 if dtype == torch.float64 else 2e-3
+    for name in ("log_lengthscale", "log_variance"):
+        got, ref = float(eng.view(name, eng.grads)), float(grads[name])
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
