@@ -55,6 +55,8 @@ struct gdrf_ctx {
   // N-side precision
   void *S, *ST, *Bm, *Sbar, *phi, *Upad, *qpart;
   void *W, *Wbar, *q, *loc, *tt, *vbar, *locbar, *asum, *mu;
+  void *g_loc, *g_tt, *g_qpart, *g_vbar, *g_locbar, *g_asum, *g_redT; double* g_redd;   // two-point evaluation (quirk Q3), allocated on first use
+  const void* mean_g; int64_t mean_g_sk, mean_g_sn;
   void *Wd;                   // W' = (dK_nm / d log lengthscale) Linv^T, allocated on first use (fixed inducing inputs, kernels without a third hyper-parameter)
   double* wdpart; hipEvent_t ev_wd;
   void *Bh, *STh, *Wh;        // 16-bit pieces of B_k, S_k^T and W (f32 contexts; split-operand MFMA forms, gemm_split.h)
@@ -222,7 +224,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->split = 0; c->wh_pieces = 0; c->ssc = nullptr; c->smx = nullptr;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0; c->mean = nullptr; c->mean_sk = c->mean_sn = 0;
-  c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr;
+  c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr; c->g_loc = nullptr; c->mean_g = nullptr; c->mean_g_sk = c->mean_g_sn = 0;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -349,6 +351,12 @@ int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
 int gdrf_set_mean(gdrf_ctx* c, const void* mean, int64_t stride_k, int64_t stride_n) {
   if (stride_k < 0 || stride_n < 0) return fail(-1, "gdrf_set_mean", "strides must be >= 0 (0 broadcasts)");
   c->mean = mean; c->mean_sk = stride_k; c->mean_sn = stride_n;
+  return 0;
+}
+
+int gdrf_set_mean_guide(gdrf_ctx* c, const void* mean, int64_t stride_k, int64_t stride_n) {
+  if (stride_k < 0 || stride_n < 0) return fail(-1, "gdrf_set_mean_guide", "strides must be >= 0 (0 broadcasts)");
+  c->mean_g = mean; c->mean_g_sk = stride_k; c->mean_g_sn = stride_n;
   return 0;
 }
 
@@ -701,15 +709,20 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
+  // parts of one evaluation: the parameter transforms, the forward over the rows (K_nm, W, loc, tt), the per-row terms, the backward
+  // over the rows.  gdrf_step_local runs them all; the two-point evaluation (step_local2: guide and model on different inputs) runs
+  // them selectively.
+  enum { SL_TRANSFORMS = 1, SL_FORWARD = 2, SL_ROWS = 4, SL_BACKWARD = 8, SL_ALL = 15 };
   static int step_local(gdrf_ctx* c, const T* X, const int32_t* ws, const T* eps, int64_t n, const T* Z, const T* params,
-                        T* redT, double* redd, hipStream_t s) {
+                        T* redT, double* redd, hipStream_t s, int mask = SL_ALL) {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
     const int64_t mm = (int64_t)Mp * Mp, ldk = c->ldk;
     int rc;
     const T* U = params + poff(c, 3);
     const T* phi_unc = params + poff(c, 4);
     const T* Sunc = params + poff(c, 5);
-    {
+    if (c->unwhitened && !(mask & SL_TRANSFORMS)) U = (const T*)c->Uw;
+    if (mask & SL_TRANSFORMS) {
       ScopedTimer tm(c, 2, s);
       dim3 g3((Mp + 255) / 256, Mp, K);
       hipLaunchKernelGGL(build_s_kernel<T>, g3, dim3(256), 0, s, Sunc, M, Mp, P(c->S), P(c->ST));
@@ -733,6 +746,8 @@ template <typename T, typename TS> struct Impl {
       }
     }
     const int64_t rtiles = (n + GDRF_TILE - 1) / GDRF_TILE;
+    const bool use_wd = wd_path(c);
+    if (mask & SL_FORWARD) {
     // (1) W = Knm Linv^T in the solve precision, stored in the N-side precision
     {
       if ((rc = knm_solve(c, X, n, s))) return rc;
@@ -756,7 +771,6 @@ template <typename T, typename TS> struct Impl {
     // W' = (dK_nm / d log lengthscale) Linv^T on the side stream, beside the K-fold contractions (its f64 MFMAs fill their stalls);
     // with it the K_nm parts of the hyper-parameter gradients are two dot products with Wbar (wbar_dot_kernel) and the backward
     // GEMM Kbar = Wbar Linv with its pass over K_nm is not needed
-    const bool use_wd = wd_path(c);
     if (use_wd) {
       if (!c->Wd) {
         void* pw = nullptr;
@@ -788,40 +802,48 @@ template <typename T, typename TS> struct Impl {
     }
     LAUNCHCHK("forward");
     HIPCHK(hipStreamWaitEvent(s, c->ev_loc, 0));
+    }
     // per-row ELBO terms and row-local backward
     int egrid;
-    {
+    if (mask & SL_ROWS) {
       ScopedTimer tm(c, 6, s);
       const bool kreg = K <= GDRF_KMAX;
-      auto lds_for = [&](int rb) {
-        return 128 + ((size_t)2 * K * V + (size_t)rb * (K + 1) * (kreg ? 1 : 2) + (size_t)rb * (V + 1)) * sizeof(T);
+      auto lds_for = [&](int rb, bool wsep) {
+        return 128 + ((size_t)2 * K * V + (size_t)rb * (K + 1) * (kreg ? 1 : 2) + (size_t)rb * (V + 1) * (wsep ? 2 : 1)) * sizeof(T);
       };
       int RB = 128;
-      while (RB > 32 && lds_for(RB) > 150 * 1024) RB >>= 1;
-      const size_t lds = lds_for(RB);
+      bool wsep = kreg && lds_for(128, true) <= 150 * 1024;      // the counts in their own LDS rows (p evaluated once) when that keeps 128 rows per block
+      while (RB > 32 && lds_for(RB, wsep) > 150 * 1024) RB >>= 1;
+      const size_t lds = lds_for(RB, wsep);
       if (lds > 150 * 1024)
         return fail(-1, "gdrf_step_local", "num_topic_categories x num_observation_categories too large: the row kernel keeps the "
                                            "(K, V) word-topic matrix and its gradient in LDS (2*K*V + 32*(2K + V + 3) elements <= 150 KB)");
-      const void* kfn = kreg ? (const void*)elbo_rows_kernel<T, true> : (const void*)elbo_rows_kernel<T, false>;
+      const void* kfn = !kreg ? (const void*)elbo_rows_kernel<T, false, false>
+                              : (wsep ? (const void*)elbo_rows_kernel<T, true, true> : (const void*)elbo_rows_kernel<T, true, false>);
       if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t nblk = (n + RB - 1) / RB;
       egrid = (int)std::min<int64_t>(nblk, c->erows_grid_cap);
-      if (kreg)
-        hipLaunchKernelGGL((elbo_rows_kernel<T, true>), dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
-                           ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
-      else
-        hipLaunchKernelGGL((elbo_rows_kernel<T, false>), dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps,
-                           ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+#define GDRF_ROWS_ARGS n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps, ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, \
+                       P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part)
+      if (!kreg) hipLaunchKernelGGL((elbo_rows_kernel<T, false, false>), dim3(egrid), dim3(RB), lds, s, GDRF_ROWS_ARGS);
+      else if (wsep) hipLaunchKernelGGL((elbo_rows_kernel<T, true, true>), dim3(egrid), dim3(RB), lds, s, GDRF_ROWS_ARGS);
+      else hipLaunchKernelGGL((elbo_rows_kernel<T, true, false>), dim3(egrid), dim3(RB), lds, s, GDRF_ROWS_ARGS);
+#undef GDRF_ROWS_ARGS
       LAUNCHCHK("elbo_rows");
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
                          (int64_t)K * V, redT + roff(c, 1));
-      if constexpr (std::is_same<T, float>::value) {
-        if (c->split) {            // block scale of diag(vbar_k) W, the scaled operand of the A_k contraction
-          if (c->split == 2)
-            hipLaunchKernelGGL(absmax_batched_kernel, dim3(64, K), dim3(256), 0, s, (const float*)c->vbar, n, ldk, c->smx + SplitLay{K}.mx_v(0));
-          split_scales(c, SPLIT_SC_V, s);
+    }
+    if (!(mask & SL_BACKWARD)) return 0;
+    if constexpr (std::is_same<T, float>::value) {
+      if (c->split) {            // block scale of diag(vbar_k) W, the scaled operand of the A_k contraction
+        const SplitLay SL{K};
+        if (c->split == 2) {
+          HIPCHK(hipMemsetAsync(c->smx + SL.mx_v(0), 0, (size_t)K * sizeof(unsigned), s));
+          HIPCHK(hipMemsetAsync(c->smx + SL.mx_wbar(), 0, sizeof(unsigned), s));
+          hipLaunchKernelGGL(absmax_batched_kernel, dim3(64, K), dim3(256), 0, s, (const float*)c->vbar, n, ldk, c->smx + SL.mx_v(0));
         }
+        split_scales(c, SPLIT_SC_V, s);
       }
     }
     // (3) Wbar
@@ -940,6 +962,69 @@ template <typename T, typename TS> struct Impl {
     }
     HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     LAUNCHCHK("reductions");
+    return 0;
+  }
+
+  // Guide and model evaluated at DIFFERENT inputs (the reference's quirk Q3, sparse_gdrf.py:376-380): forward at the guide's inputs,
+  // keep its (loc, tt, q); forward at the model's; two-point row terms; backward through the model-side predictive; forward at the
+  // guide's inputs again (the N x M intermediates are not kept twice) and backward through the guide-side predictive; the two
+  // payloads add.  ~2.5 x the cost of a step - this path exists for parity with the reference on non-unit worlds, not for speed.
+  static int step_local2(gdrf_ctx* c, const T* Xm, const T* Xg, const int32_t* ws, const T* eps, int64_t n, const T* Z, const T* params,
+                         T* redT, double* redd, hipStream_t s) {
+    const int K = c->K, V = c->V;
+    const int64_t ldk = c->ldk, kn = (int64_t)K * ldk, nq = (int64_t)((c->Mp + 63) / 64) * ldk;
+    const int64_t nT = roff(c, 4), nd = 8 + (int64_t)c->M * c->D;
+    int rc;
+    if (!c->g_loc) {
+      void** ps[] = {&c->g_loc, &c->g_tt, &c->g_qpart, &c->g_vbar, &c->g_locbar, &c->g_asum, &c->g_redT, (void**)&c->g_redd};
+      const size_t sz[] = {(size_t)kn * c->esz, (size_t)kn * c->esz, (size_t)nq * c->esz, (size_t)kn * c->esz, (size_t)kn * c->esz,
+                           (size_t)ldk * c->esz, (size_t)nT * c->esz, (size_t)nd * sizeof(double)};
+      for (int i = 0; i < 8; ++i) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, sz[i]);
+        if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(two-point scratch)", hipGetErrorString(e));
+        *ps[i] = p; c->allocs.push_back(p);
+      }
+    }
+    if ((rc = step_local(c, Xg, ws, eps, n, Z, params, redT, redd, s, SL_TRANSFORMS | SL_FORWARD))) return rc;
+    HIPCHK(hipMemcpyAsync(c->g_loc, c->loc, (size_t)kn * c->esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->g_tt, c->tt, (size_t)kn * c->esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->g_qpart, c->qpart, (size_t)nq * c->esz, hipMemcpyDeviceToDevice, s));
+    if ((rc = step_local(c, Xm, ws, eps, n, Z, params, redT, redd, s, SL_FORWARD))) return rc;
+    {
+      ScopedTimer tm(c, 6, s);
+      const int RB = 64;
+      const size_t lds = 128 + ((size_t)2 * K * V + (size_t)2 * RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T);
+      if (lds > 150 * 1024) return fail(-1, "gdrf_step_local2", "num_topic_categories x num_observation_categories too large for the row kernel's LDS");
+      if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)elbo_rows2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int egrid = (int)std::min<int64_t>((n + RB - 1) / RB, c->erows_grid_cap);
+      hipLaunchKernelGGL(elbo_rows2_kernel<T>, dim3(egrid), dim3(RB), lds, s, n, K, V, c->hyp, nct<TS>(c), P(c->qpart), P(c->loc), P(c->tt),
+                         (const T*)c->g_qpart, (const T*)c->g_loc, (const T*)c->g_tt, eps, ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk,
+                         c->mean_sn, (const T*)c->mean_g, c->mean_g_sk, c->mean_g_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum),
+                         (T*)c->g_vbar, (T*)c->g_locbar, (T*)c->g_asum, P(c->mu), c->dpart, P(c->phibar_part));
+      LAUNCHCHK("elbo_rows2");
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
+                         (int64_t)K * V, redT + roff(c, 1));
+    }
+    // backward through the model-side predictive (the buffers hold its W), payload aside
+    if ((rc = step_local(c, Xm, ws, eps, n, Z, params, redT, redd, s, SL_BACKWARD))) return rc;
+    HIPCHK(hipMemcpyAsync(c->g_redT, redT, (size_t)nT * c->esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->g_redd, redd, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, s));
+    // the guide side: its forward again, its row-local gradients in place of the model's
+    if ((rc = step_local(c, Xg, ws, eps, n, Z, params, redT, redd, s, SL_FORWARD))) return rc;
+    std::swap(c->vbar, c->g_vbar); std::swap(c->locbar, c->g_locbar); std::swap(c->asum, c->g_asum);
+    rc = step_local(c, Xg, ws, eps, n, Z, params, redT, redd, s, SL_BACKWARD);
+    std::swap(c->vbar, c->g_vbar); std::swap(c->locbar, c->g_locbar); std::swap(c->asum, c->g_asum);
+    if (rc) return rc;
+    // payload = model side + guide side: ubar, A_k, G^T (not the phibar block, which the row kernel wrote once) and red_d[4..]
+    auto add = [&](int64_t off, int64_t len) {
+      hipLaunchKernelGGL(add_into_kernel<T>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, len, (const T*)c->g_redT + off, redT + off);
+    };
+    add(roff(c, 0), roff(c, 1) - roff(c, 0));
+    add(roff(c, 2), roff(c, 5) - roff(c, 2));
+    hipLaunchKernelGGL(add_into_kernel<double>, dim3((unsigned)((nd - 4 + 255) / 256)), dim3(256), 0, s, nd - 4, (const double*)c->g_redd + 4, redd + 4);
+    LAUNCHCHK("step_local2");
     return 0;
   }
 
@@ -1120,6 +1205,15 @@ int gdrf_step_local(gdrf_ctx* c, const void* X, const int32_t* ws, const void* e
   if (n < 1 || n > c->ncap) return fail(-1, "gdrf_step_local", "n_local outside [1, n_cap]");
   hipStream_t s = (hipStream_t)stream;
   TYPED3(c, step_local, c, (const T*)X, ws, (const T*)eps, n, (const T*)Z, (const T*)params, (T*)redT, redd, s);
+}
+
+int gdrf_step_local2(gdrf_ctx* c, const void* X_model, const void* X_guide, const int32_t* ws, const void* eps, int64_t n, const void* Z,
+                     const void* params, void* redT, double* redd, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (n < 1 || n > c->ncap) return fail(-1, "gdrf_step_local2", "n_local outside [1, n_cap]");
+  if (c->Tst) return fail(-1, "gdrf_step_local2", "needs the dense Wbar form (GDRF_STORE_T_OFF)");
+  hipStream_t s = (hipStream_t)stream;
+  TYPED3(c, step_local2, c, (const T*)X_model, (const T*)X_guide, ws, (const T*)eps, n, (const T*)Z, (const T*)params, (T*)redT, redd, s);
 }
 
 int gdrf_step_finish(gdrf_ctx* c, const void* Z, const void* params, const void* redT, const double* redd, double n_global,

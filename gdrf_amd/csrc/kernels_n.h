@@ -852,7 +852,7 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
 // =====================================================================================
 #define GDRF_KMAX 32
 
-template <typename T, bool KREG>
+template <typename T, bool KREG, bool WSEP = true>
 __global__ __launch_bounds__(128) void elbo_rows_kernel(
     int64_t nrows, int K, int V, const Hyper* __restrict__ h,
     const T* __restrict__ qpart, int nqpart, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps,
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
   T* thS = accS + K * V;                                // [RB][K+1]
   T* pbS = thS + RB * (K + 1);                          // [RB][V+1]
   T* tbS = pbS + RB * (V + 1);                          // [RB][K+1], !KREG only
+  T* wS = tbS + (KREG ? 0 : RB * (K + 1));              // [RB][V+1] the counts, WSEP only (else they share pbS and p is evaluated twice)
   for (int e = threadIdx.x; e < K * V; e += RB) { phiS[e] = phi[e]; accS[e] = 0; }
   __syncthreads();
   const T var = (T)h->var, eta = (T)h->noise;
@@ -882,20 +883,22 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     T* th = thS + threadIdx.x * (K + 1);
     T* pb = pbS + threadIdx.x * (V + 1);
     T* tbl = tbS + threadIdx.x * (K + 1);
-    {   // counts of this block's rows -> pbS (as T): element e of the contiguous RB x V block is row e / V, taxon e % V
+    T* const cntS = WSEP ? wS : pbS;
+    const T* wrow = cntS + threadIdx.x * (V + 1);
+    {   // counts of this block's rows -> LDS (as T): element e of the contiguous RB x V block is row e / V, taxon e % V
       const int64_t e0 = blk * RB * (int64_t)V;
       int64_t cnt = (nrows - blk * RB < RB ? nrows - blk * RB : (int64_t)RB) * V;
       const int32_t* src = ws + e0;
       const int head = (int)((4 - (e0 & 3)) & 3);         // elements in front of the first 16-byte aligned one
-      for (int64_t e = threadIdx.x; e < head && e < cnt; e += RB) pbS[(e / V) * (V + 1) + e % V] = (T)src[e];
+      for (int64_t e = threadIdx.x; e < head && e < cnt; e += RB) cntS[(e / V) * (V + 1) + e % V] = (T)src[e];
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       const int64_t nvec = cnt > head ? (cnt - head) >> 2 : 0;
       for (int64_t q = threadIdx.x; q < nvec; q += RB) {
         const i32x4 w4 = *reinterpret_cast<const i32x4*>(src + head + 4 * q);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int64_t e = head + 4 * q + j; pbS[(e / V) * (V + 1) + e % V] = (T)w4[j]; }
+        for (int j = 0; j < 4; ++j) { const int64_t e = head + 4 * q + j; cntS[(e / V) * (V + 1) + e % V] = (T)w4[j]; }
       }
-      for (int64_t e = head + 4 * nvec + threadIdx.x; e < cnt; e += RB) pbS[(e / V) * (V + 1) + e % V] = (T)src[e];
+      for (int64_t e = head + 4 * nvec + threadIdx.x; e < cnt; e += RB) cntS[(e / V) * (V + 1) + e % V] = (T)src[e];
     }
     __syncthreads();
     T v[KR], mu[KR], ep[KR];
@@ -933,15 +936,17 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
       for (int vv = 0; vv < V; ++vv) {
         T p = 0;
         for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
+        if (WSEP) pb[vv] = p;
         ps += p;
       }
       const T ips = T(1) / ps;
       T llw = 0;
       for (int vv = 0; vv < V; ++vv) {
-        T p = 0;
-        for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
+        T p;
+        if (WSEP) p = pb[vv];
+        else { p = 0; for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv]; }
         const T ph = p * ips;
-        const T wv = pb[vv];
+        const T wv = wrow[vv];
         const bool inr = (ph > feps) && (ph < T(1) - feps);
         const T phc = fmin(fmax(ph, feps), T(1) - feps);
         llw += wv * t_log<T>(phc);
@@ -1008,6 +1013,121 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     dpart[4 * (int64_t)blockIdx.x + 2] = b2; dpart[4 * (int64_t)blockIdx.x + 3] = b3;
   }
   for (int e = threadIdx.x; e < K * V; e += RB) phibar_part[(int64_t)blockIdx.x * K * V + e] = accS[e];
+}
+
+// The same per-row terms when the guide and the model evaluate the GP predictive at DIFFERENT inputs - the reference's quirk Q3
+// (gdrf/models/sparse_gdrf.py:376-380: for a world other than the unit cube the guide scales its inputs twice, the model once).
+// Guide side (subscript g): mu = loc_g + v_g eps, log q = -log v_g - eps^2 / 2.  Model side (m): log p = -log s_m - (d / s_m)^2 / 2 with
+// s_m = v_m + noise, d = mu - loc_m (- the model-side mean).  With mub the pull-back of the likelihood through the softmax link:
+//   locbar_g = mub - d / s_m^2 ;  vbar_g = locbar_g eps + 1 / v_g ;  locbar_m = d / s_m^2 ;  vbar_m = -1 / s_m + d^2 / s_m^3 (= d/d noise)
+// (for identical inputs their sums are the single-point formulas of elbo_rows_kernel).  One thread per row, any K; not a hot path.
+template <typename T>
+__global__ __launch_bounds__(64) void elbo_rows2_kernel(
+    int64_t nrows, int K, int V, const Hyper* __restrict__ h, int nqpart,
+    const T* __restrict__ qpart_m, const T* __restrict__ loc_m, const T* __restrict__ tt_m,
+    const T* __restrict__ qpart_g, const T* __restrict__ loc_g, const T* __restrict__ tt_g,
+    const T* __restrict__ eps, int64_t ldk, int64_t lde, const int32_t* __restrict__ ws, const T* __restrict__ phi,
+    const T* __restrict__ mean_m, int64_t mm_sk, int64_t mm_sn, const T* __restrict__ mean_g, int64_t mg_sk, int64_t mg_sn,
+    T* __restrict__ qout, T* __restrict__ vbar_m, T* __restrict__ locbar_m, T* __restrict__ asum_m,
+    T* __restrict__ vbar_g, T* __restrict__ locbar_g, T* __restrict__ asum_g, T* __restrict__ mu_out,
+    double* __restrict__ dpart /*[grid][4]*/, T* __restrict__ phibar_part /*[grid][K*V]*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int RB = blockDim.x;
+  double* scratch = reinterpret_cast<double*>(smem);
+  T* phiS = reinterpret_cast<T*>(smem + 128);           // [K*V]
+  T* accS = phiS + K * V;                               // [K*V]
+  T* thS = accS + K * V;                                // [RB][K+1]
+  T* pbS = thS + RB * (K + 1);                          // [RB][V+1]
+  T* tbS = pbS + RB * (V + 1);                          // [RB][K+1]
+  for (int e = threadIdx.x; e < K * V; e += RB) { phiS[e] = phi[e]; accS[e] = 0; }
+  __syncthreads();
+  const T var = (T)h->var, eta = (T)h->noise, feps = t_eps<T>();
+  double s_site = 0, s_llw = 0, s_noise = 0, s_vd = 0;
+  const int64_t nblk = (nrows + RB - 1) / RB;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t n = blk * RB + threadIdx.x;
+    const bool ok = n < nrows;
+    T* th = thS + threadIdx.x * (K + 1);
+    T* pb = pbS + threadIdx.x * (V + 1);
+    T* tb = tbS + threadIdx.x * (K + 1);
+    if (ok) {
+      T qm = 0, qg = 0;
+      for (int c = 0; c < nqpart; ++c) { qm += qpart_m[(int64_t)c * ldk + n]; qg += qpart_g[(int64_t)c * ldk + n]; }
+      qout[n] = qm;
+      const T am = (var - qm > T(0)) ? T(1) : T(0), ag = (var - qg > T(0)) ? T(1) : T(0);
+      const T v0m = am * (var - qm), v0g = ag * (var - qg);
+      auto mu_of = [&](int k, T& vg, T& ek) {
+        ek = eps[(int64_t)k * lde + n];
+        vg = v0g + tt_g[(int64_t)k * ldk + n];
+        T m = loc_g[(int64_t)k * ldk + n] + vg * ek;
+        if (mean_g) m += mean_g[(int64_t)k * mg_sk + n * mg_sn];
+        return m;
+      };
+      T mx = -3.0e38f;
+      for (int k = 0; k < K; ++k) { T vg, ek; const T m = mu_of(k, vg, ek); th[k] = m; mx = fmax(mx, m); }
+      T se = 0;
+      for (int k = 0; k < K; ++k) { const T e = t_exp<T>(th[k] - mx); th[k] = e; se += e; }
+      const T ise = T(1) / se;
+      for (int k = 0; k < K; ++k) th[k] *= ise;
+      T ps = 0;
+      for (int vv = 0; vv < V; ++vv) { T p = 0; for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv]; pb[vv] = p; ps += p; }
+      const T ips = T(1) / ps;
+      T llw = 0;
+      for (int vv = 0; vv < V; ++vv) {
+        const T p = pb[vv], ph = p * ips, wv = (T)ws[n * V + vv];
+        const bool inr = (ph > feps) && (ph < T(1) - feps);
+        llw += wv * t_log<T>(fmin(fmax(ph, feps), T(1) - feps));
+        pb[vv] = inr ? wv / p : T(0);
+      }
+      s_llw += (double)llw;
+      T dot = 0;
+      for (int k = 0; k < K; ++k) { T sum = 0; for (int vv = 0; vv < V; ++vv) sum += phiS[k * V + vv] * pb[vv]; tb[k] = sum; dot += th[k] * sum; }
+      T site = 0, ng = 0, vsm = 0, vsg = 0;
+      for (int k = 0; k < K; ++k) {
+        T vg, ek;
+        const T mu = mu_of(k, vg, ek);
+        const T vm = v0m + tt_m[(int64_t)k * ldk + n], sm = vm + eta;
+        T lm = loc_m[(int64_t)k * ldk + n];
+        if (mean_m) lm += mean_m[(int64_t)k * mm_sk + n * mm_sn];
+        const T d = mu - lm, mub = th[k] * (tb[k] - dot);
+        site += -t_log<T>(sm) - T(0.5) * (d / sm) * (d / sm) + t_log<T>(vg) + T(0.5) * ek * ek;
+        const T lbm = d / (sm * sm), vbm = -T(1) / sm + d * d / (sm * sm * sm);
+        const T lbg = mub - lbm, vbg = lbg * ek + T(1) / vg;
+        ng += vbm;
+        vbar_m[(int64_t)k * ldk + n] = vbm; locbar_m[(int64_t)k * ldk + n] = lbm;
+        vbar_g[(int64_t)k * ldk + n] = vbg; locbar_g[(int64_t)k * ldk + n] = lbg;
+        if (mu_out) mu_out[(int64_t)k * ldk + n] = mu;
+        vsm += vbm; vsg += vbg;
+      }
+      asum_m[n] = am * vsm; asum_g[n] = ag * vsg;
+      s_site += (double)site; s_noise += (double)ng; s_vd += (double)(am * vsm + ag * vsg);
+    } else {
+      for (int k = 0; k < K; ++k) th[k] = 0;
+      for (int vv = 0; vv < V; ++vv) pb[vv] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * V; e += RB) {
+      const int k = e / V, vv = e - k * V;
+      T sum = 0;
+      for (int r = 0; r < RB; ++r) sum += thS[r * (K + 1) + k] * pbS[r * (V + 1) + vv];
+      accS[e] += sum;
+    }
+    __syncthreads();
+  }
+  const double b0 = block_sum(s_site, scratch), b1 = block_sum(s_llw, scratch);
+  const double b2 = block_sum(s_noise, scratch), b3 = block_sum(s_vd, scratch);
+  if (threadIdx.x == 0) {
+    dpart[4 * (int64_t)blockIdx.x + 0] = b0; dpart[4 * (int64_t)blockIdx.x + 1] = b1;
+    dpart[4 * (int64_t)blockIdx.x + 2] = b2; dpart[4 * (int64_t)blockIdx.x + 3] = b3;
+  }
+  for (int e = threadIdx.x; e < K * V; e += RB) phibar_part[(int64_t)blockIdx.x * K * V + e] = accS[e];
+}
+
+// y[i] += x[i]
+template <typename T>
+__global__ void add_into_kernel(int64_t n, const T* __restrict__ x, T* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
 }
 
 // vmax[k] = bits of max_n |x[k][n]| (floats are ordered like their bit patterns when non-negative); vmax zeroed by the caller

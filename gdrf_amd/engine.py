@@ -272,13 +272,23 @@ class Engine:
         raise RuntimeError("reached max jitter, covariance is unstable")
 
     def loss_and_grads(self, xs, ws, eps, n_global: Optional[int] = None, ll_const: Optional[float] = None,
-                       force_level: Optional[int] = None, renyi_alpha: Optional[float] = None, mean: Optional[torch.Tensor] = None):
+                       force_level: Optional[int] = None, renyi_alpha: Optional[float] = None, mean: Optional[torch.Tensor] = None,
+                       xs_guide: Optional[torch.Tensor] = None, mean_guide: Optional[torch.Tensor] = None):
         """One ELBO evaluation + backward.  Leaves d loss/d unconstrained in self.grads (device) and
         returns nothing host-side; call read_out() for the loss.  ``mean``: the values of the model's mean_function on these
-        rows, broadcastable to (K, n) (gdrf/models/sparse_gdrf.py:346,395); None = zero_mean."""
+        rows, broadcastable to (K, n) (gdrf/models/sparse_gdrf.py:346,395); None = zero_mean.  ``xs_guide``: the inputs the
+        GUIDE's predictive is evaluated at when they differ from the model's (quirk Q3: the reference's guide scales twice,
+        sparse_gdrf.py:376-380), with ``mean_guide`` the mean_function values there; None = the same inputs (one evaluation)."""
         self._chk_rows(xs, ws)
         n = xs.shape[0]
         self._set_mean(mean, n)
+        self._xs_guide = None
+        if xs_guide is not None:
+            self._chk_rows(xs_guide)
+            if xs_guide.shape != xs.shape:
+                raise ValueError("xs_guide must have the shape of xs")
+            self._xs_guide = xs_guide
+            self._set_mean(mean_guide, n, guide=True)
         if eps.dim() == 2:
             eps = eps.unsqueeze(0)
         P = eps.shape[0]                          # particles (Trace_ELBO num_particles): the estimator is their mean
@@ -322,18 +332,19 @@ class Engine:
                 self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
         self._guess_level = self.last_jitter_level if force_level is None else None
 
-    def _set_mean(self, mean, n: int):
+    def _set_mean(self, mean, n: int, guide: bool = False):
+        fn = self.lib.gdrf_set_mean_guide if guide else self.lib.gdrf_set_mean
         if mean is None:
-            self._mean = None
-            _lib.check(self.lib.gdrf_set_mean(self.ctx, None, 0, 0), "gdrf_set_mean")
+            setattr(self, "_mean_g" if guide else "_mean", None)
+            _lib.check(fn(self.ctx, None, 0, 0), "gdrf_set_mean")
             return
         mean = torch.as_tensor(mean).detach().to(device=self.device, dtype=self.dtype)
         try:
             mean = mean.expand(self.K, n)                       # (n,), (K, 1), (K, n), scalars: torch broadcasting, as f_loc + mean
         except RuntimeError:
             raise ValueError(f"mean_function returned shape {tuple(mean.shape)}, not broadcastable to ({self.K}, {n})") from None
-        self._mean = mean                                       # keeps the storage alive while the context borrows it
-        _lib.check(self.lib.gdrf_set_mean(self.ctx, mean.data_ptr(), mean.stride(0), mean.stride(1)), "gdrf_set_mean")
+        setattr(self, "_mean_g" if guide else "_mean", mean)    # keeps the storage alive while the context borrows it
+        _lib.check(fn(self.ctx, mean.data_ptr(), mean.stride(0), mean.stride(1)), "gdrf_set_mean")
 
     def _probe_level(self, stream_ptr: int) -> int:
         """First cumulative-jitter level whose array-precision Cholesky succeeds (probe only; raises past maxjitter)."""
@@ -362,10 +373,16 @@ class Engine:
         if renyi_alpha is not None and float(renyi_alpha) == 1.0:
             raise ValueError("RenyiELBO: alpha must differ from 1")
         Ts, ds = [], []
+        xg = getattr(self, "_xs_guide", None)
         for p in range(P):
-            _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n, self.Z.data_ptr(),
-                                                self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
-                       "gdrf_step_local")
+            if xg is None:
+                _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n, self.Z.data_ptr(),
+                                                    self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
+                           "gdrf_step_local")
+            else:
+                _lib.check(self.lib.gdrf_step_local2(self.ctx, xs.data_ptr(), xg.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n,
+                                                     self.Z.data_ptr(), self.params.data_ptr(), self.red_T.data_ptr(),
+                                                     self.red_d.data_ptr(), s), "gdrf_step_local2")
             if P > 1 or renyi_alpha is not None:
                 Ts.append(self.red_T.clone()); ds.append(self.red_d.clone())
         if renyi_alpha is not None:

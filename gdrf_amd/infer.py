@@ -89,8 +89,9 @@ class SVI:
         self.optim._bind(eng)
         n = xs_s.shape[0]
         eps = self._eps(eng, eps, n)
+        xs_g = model._guide_inputs(xs_s)
         eng.loss_and_grads(xs_s, ws_d, eps, n_global=1.0 / self.scale, renyi_alpha=getattr(self.loss, "alpha", None),
-                           mean=model._mean_values(xs_s))
+                           mean=model._mean_values(xs_s), xs_guide=xs_g, mean_guide=None if xs_g is None else model._mean_values(xs_g))
         self.optim._step()
         out = eng.read_out()
         self.steps_taken += 1
@@ -105,8 +106,10 @@ class SVI:
         xs_s, ws_d = model._prepare_inputs(xs, ws)
         eng = model._engine_for(xs_s.shape[0])
         n = xs_s.shape[0]
+        xs_g = model._guide_inputs(xs_s)
         eng.loss_and_grads(xs_s, ws_d, self._eps(eng, eps, n), n_global=1.0 / self.scale,
-                           renyi_alpha=getattr(self.loss, "alpha", None), mean=model._mean_values(xs_s))
+                           renyi_alpha=getattr(self.loss, "alpha", None), mean=model._mean_values(xs_s), xs_guide=xs_g,
+                           mean_guide=None if xs_g is None else model._mean_values(xs_g))
         return float(eng.read_out()["loss"])
 
     def _eps(self, eng, eps, n):

@@ -94,6 +94,7 @@ class SparseMultinomialGDRF:
         mfma_mode: str = "auto",
         inducing_points: Optional[torch.Tensor] = None,
         seed: Optional[int] = None,
+        guide_rescale: bool = True,
         **kwargs,
     ):
         if link_function is not None:
@@ -106,6 +107,10 @@ class SparseMultinomialGDRF:
         # abstract_gdrf.py:38-48: evaluated on the scaled inputs every step; its values are data to the fused step (no gradient
         # flows into a mean_function's own parameters)
         self._mean_function = mean_function
+        # quirk Q3 (sparse_gdrf.py:376-380): the reference's guide scales its inputs twice.  True reproduces that (for a world
+        # other than the unit cube the step then evaluates the GP predictive at two input sets, gdrf_step_local2); False scales
+        # once on both sides.  No effect for the unit-cube world train() builds.
+        self._guide_rescale = bool(guide_rescale)
         self._randomize_metric, self._randomize_iters = randomize_metric, int(randomize_iters)
         if not isinstance(kernel, Kernel):
             raise TypeError("kernel must be a gdrf_amd.kernels.RBF or Matern52")
@@ -229,9 +234,17 @@ class SparseMultinomialGDRF:
         lo, hi = self._lower.to(input), self._upper.to(input)
         return input.shape[-1] == self._n_dims and bool(((input - lo > -epsilon) & (input - hi < epsilon)).all())
 
+    def _guide_inputs(self, xs_scaled: torch.Tensor) -> Optional[torch.Tensor]:
+        """The inputs the reference's guide ends up evaluating its predictive at: scale(scale(xs)) (quirk Q3); None when that is
+        what the model sees too (unit-cube world, or guide_rescale=False)."""
+        unit = all(a == 0.0 and b == 1.0 for a, b in self._world)
+        if unit or not self._guide_rescale:
+            return None
+        return self.scale(xs_scaled.double()).to(self.dtype).contiguous()
+
     def _prepare_inputs(self, xs, ws=None):
         """@scale_decorator semantics: bounds assertion then the affine map to the unit cube (identity for the
-        world train() builds, train_script.py:261-271).  The guide's second scaling (quirk Q3) is NOT reproduced."""
+        world train() builds, train_script.py:261-271).  The guide's second scaling (quirk Q3): _guide_inputs."""
         xs = torch.as_tensor(xs)
         if xs.dim() == 1:
             xs = xs.unsqueeze(-1)

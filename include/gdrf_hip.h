@@ -137,6 +137,16 @@ int gdrf_factorize(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, dou
 int gdrf_step_local(gdrf_ctx* ctx, const void* X_dev, const int32_t* ws_dev, const void* eps_dev, int64_t n_local,
                     const void* Z_dev, const void* params_dev, void* red_T_dev, double* red_d_dev, void* stream);
 
+/* The same with the guide and the model evaluated at DIFFERENT inputs: the reference's guide scales its inputs twice
+ * (gdrf/models/sparse_gdrf.py:376 @scale_decorator and :380 `xs = self.scale(xs)`), its model once (:324), so for a world other
+ * than the unit cube the guide's gp.util.conditional sees X_guide = scale(scale(xs)) and the model's X_model = scale(xs).
+ * mu is drawn from the guide-side predictive, log q uses it, log p(mu) the model-side one; both are differentiated.  About 2.5 x
+ * the work of gdrf_step_local (two forwards and backwards, the guide's forward twice); the mean_function values of the guide side
+ * come from gdrf_set_mean_guide, the model side's from gdrf_set_mean. */
+int gdrf_step_local2(gdrf_ctx* ctx, const void* X_model_dev, const void* X_guide_dev, const int32_t* ws_dev, const void* eps_dev,
+                     int64_t n_local, const void* Z_dev, const void* params_dev, void* red_T_dev, double* red_d_dev, void* stream);
+int gdrf_set_mean_guide(gdrf_ctx* ctx, const void* mean, int64_t stride_k, int64_t stride_n);
+
 /* Replicated epilogue: Cholesky / kernel hyper-parameter backward, constraint Jacobians, Dirichlet
  * term, loss.  grads (same layout as params) = d loss / d unconstrained.  out_d (8 doubles) =
  * {loss, cholesky_failed, site_sum, loglik_sum, log_prior_phi, ...}.  ll_const = the data-only constant of the

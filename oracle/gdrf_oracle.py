@@ -170,8 +170,15 @@ class RefShapedGDRF:
                  dirichlet_param=0.01, jitter=1e-8, maxjitter=15, noise=1.0, dtype=torch.float64,
                  Z: Optional[torch.Tensor] = None, optimizer="adam", lr=1e-3,
                  force_jitter_level: Optional[int] = None, learn_inducing: bool = False, scale_mixture: float = 1.0,
-                 whiten: bool = True, mean_function=None):
+                 whiten: bool = True, mean_function=None, world: Optional[Sequence[Tuple[float, float]]] = None,
+                 guide_rescale: bool = True):
         self.dtype = dtype
+        # topic_model.py:148-198: inputs are mapped to the unit cube by (x - lower) / delta.  With world=None the inputs are taken as
+        # already scaled (what train() builds: world = [(0, 1)]^D, train_script.py:261-271).  Quirk Q3 (sparse_gdrf.py:376-380): the
+        # guide is decorated with @scale_decorator AND calls self.scale(xs) again, so for a non-unit world the guide's conditional
+        # is evaluated at the DOUBLY scaled inputs while the model's sees the singly scaled ones; guide_rescale=True restates that.
+        self.world = None if world is None else [(float(a), float(b)) for a, b in world]
+        self.guide_rescale = bool(guide_rescale)
         self.mean_function = mean_function          # abstract_gdrf.py:33-48; None = zero_mean (abstract_gdrf.py:17-18)
         self.kind = kind
         self.K = K
@@ -181,8 +188,12 @@ class RefShapedGDRF:
         self.V = self.ws.shape[1]
         self.jitter, self.maxjitter = jitter, maxjitter
         self.force_jitter_level = force_jitter_level
-        world = [(0.0, 1.0)] * self.D
-        self.Z = (grid_inducing_points(world, list(n_points)) if Z is None else torch.as_tensor(Z)).to(dtype)
+        unit = [(0.0, 1.0)] * self.D
+        if self.world is not None:
+            self._lower = torch.tensor([b[0] for b in self.world], dtype=dtype)
+            self._delta = torch.tensor([b[1] - b[0] for b in self.world], dtype=dtype)
+        # sparse_gdrf.py:61-77: grid points are laid out in the world and then scaled: the same unit-cube grid
+        self.Z = (grid_inducing_points(unit, list(n_points)) if Z is None else torch.as_tensor(Z)).to(dtype)
         self.M = self.Z.shape[0]
         self.alpha = validate_dirichlet_param(dirichlet_param, K, self.V).to(dtype)
         # unconstrained parameters (PyroParam storage)
@@ -236,6 +247,10 @@ class RefShapedGDRF:
             scale_mixture=p["log_scale_mixture"].exp() if "log_scale_mixture" in p else None,
         )
 
+    def scale(self, xs: torch.Tensor) -> torch.Tensor:
+        """topic_model.py:168-169 (identity when no world was given)."""
+        return xs if self.world is None else (xs - self._lower) / self._delta
+
     def _luu(self, c):
         Zc = self.inducing()
         Kuu = kernel_matrix(self.kind, Zc, Zc, c["lengthscale"], c["variance"], c["scale_mixture"]).contiguous()
@@ -250,12 +265,14 @@ class RefShapedGDRF:
         scale = 1.0 / (n_global if n_global is not None else self.N)   # train_script.py:365 (Q9)
         eps = torch.as_tensor(eps).to(self.dtype)
         c = self.constrained()
+        xs = self.scale(xs)                                # @scale_decorator("xs") on model and guide
+        xs_g = self.scale(xs) if self.guide_rescale else xs   # the guide's own `xs = self.scale(xs)` (quirk Q3)
         # guide: sparse_gdrf.py:375-409
         Luu = self._luu(c)
-        f_loc, f_var = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],
+        f_loc, f_var = conditional(self.kind, xs_g, self.inducing(), c["lengthscale"], c["variance"],
                                    c["u_loc"], c["u_scale_tril"], Luu, c["scale_mixture"], self.whiten)
         if self.mean_function is not None:
-            f_loc = f_loc + self.mean_function(xs)        # sparse_gdrf.py:395
+            f_loc = f_loc + self.mean_function(xs_g)      # sparse_gdrf.py:395
         q_mu = Normal(f_loc, f_var)                       # Q1: variance passed as scale
         mu = f_loc + f_var * eps                          # rsample with injected eps
         lq_mu = q_mu.log_prob(mu).sum()
@@ -365,7 +382,7 @@ class RefShapedGDRF:
     # ---- predictive path (sparse_gdrf.py:161-186, abstract_gdrf.py:113-139) --
     @torch.no_grad()
     def log_topic_probs(self, xs=None):
-        xs = self.xs if xs is None else torch.as_tensor(xs).to(self.dtype)
+        xs = self.scale(self.xs if xs is None else torch.as_tensor(xs).to(self.dtype))     # scaled once (sparse_gdrf.py:161-162)
         c = self.constrained()
         Luu = self._luu(c)
         f_loc, _ = conditional(self.kind, xs, self.inducing(), c["lengthscale"], c["variance"],

@@ -181,3 +181,84 @@ def test_hyper_gradients_through_the_derivative_product(dtype, kind, monkeypatch
     for name in ("log_lengthscale", "log_variance"):
         got, ref = float(eng.view(name, eng.grads)), float(grads[name])
         assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
+
+
+# ---- non-unit worlds: the reference's guide scales its inputs twice (quirk Q3, gdrf/models/sparse_gdrf.py:376-380) -------------------
+WORLD = [(2.0, 5.0), (-1.0, 3.0)]
+
+
+def _world_oracle(dtype, guide_rescale=True, mean_function=None, seed=4):
+    from oracle.gdrf_oracle import RefShapedGDRF
+    from gdrf_amd.data import synth_circles
+    xs, ws, _ = synth_circles(17, 11, 9, 3, seed=seed)
+    lower = torch.tensor([w[0] for w in WORLD], dtype=torch.float64)
+    delta = torch.tensor([w[1] - w[0] for w in WORLD], dtype=torch.float64)
+    xs_w = torch.from_numpy(xs).double() * delta + lower                       # observations in world coordinates
+    m = RefShapedGDRF(xs_w, ws, kind="rbf", K=3, n_points=(5, 4), lengthscale=0.3, dtype=dtype, jitter=1e-6, world=WORLD,
+                      guide_rescale=guide_rescale, optimizer="adam", lr=1e-2, mean_function=mean_function)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64).to(dtype))
+        m.params["phi_unc"].add_(0.5 * torch.randn(m.params["phi_unc"].shape, generator=g, dtype=torch.float64).to(dtype))
+        m.params["u_scale_tril_unc"].add_(0.1 * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril().to(dtype))
+    eps = torch.randn(3, m.N, generator=g, dtype=torch.float64).to(dtype)
+    return m, eps, xs_w
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("with_mean", [False, True])
+def test_non_unit_world_guide_scales_twice_like_the_reference(dtype, with_mean):
+    """Loss and every gradient of the two-point evaluation (gdrf_step_local2: guide at scale(scale(xs)), model at scale(xs)) against
+    autograd through the reference-shaped oracle with the same double scaling."""
+    mf = (lambda x: 1.5 * x[:, 0] - 0.7 * x[:, 1]) if with_mean else None
+    m, eps, xs_w = _world_oracle(torch.float64, mean_function=mf)
+    loss_ref, grads_ref = m.loss_and_grads(eps)
+    eng = engine_from_oracle(m, dtype=dtype)
+    xs_m = m.scale(xs_w)
+    xs_g = m.scale(xs_m)
+    kw = {}
+    if with_mean:
+        kw = dict(mean=dev(mf(xs_m), eng), mean_guide=dev(mf(xs_g), eng))
+    eng.loss_and_grads(dev(xs_m, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), xs_guide=dev(xs_g, eng), force_level=m.last_jitter_level, **kw)
+    out = eng.read_out()
+    tl, tg = (1e-9, 1e-7) if dtype == torch.float64 else (2e-5, 2e-2)
+    assert abs(out["loss"] - loss_ref) <= max(tl, LOSS_TOL_VS_TORCH) * abs(loss_ref), (out["loss"], loss_ref)
+    gv = eng.named_views(eng.grads)
+    for name in eng.PARAM_NAMES:
+        assert relerr(gv[name].cpu().numpy(), grads_ref[name].numpy()) < tg, name
+    # it IS a different objective from scaling once on both sides
+    m1, _, _ = _world_oracle(torch.float64, guide_rescale=False, mean_function=mf)
+    assert abs(float(m1.loss(eps).detach()) - loss_ref) > 1e-3 * abs(loss_ref)
+
+
+def test_non_unit_world_through_the_model_surface():
+    """SparseMultinomialGDRF(world=...) + SVI.step: three Adam steps follow the oracle with the reference's double scaling
+    (default), and guide_rescale=False reproduces the unit-cube model on the scaled inputs."""
+    from gdrf_amd import poutine
+    from gdrf_amd.infer import SVI, Trace_ELBO
+    from gdrf_amd.kernels import RBF
+    from gdrf_amd.models import SparseMultinomialGDRF
+    from gdrf_amd.optim import Adam
+    device = "cuda:0"
+    for rescale in (True, False):
+        m, eps0, xs_w = _world_oracle(torch.float64, guide_rescale=rescale)
+        model = SparseMultinomialGDRF(xs=xs_w.to(device), ws=m.ws.to(device), world=WORLD,
+                                      kernel=RBF(input_dim=2, lengthscale=torch.tensor(0.3), variance=torch.tensor(25.0)),
+                                      num_observation_categories=9, num_topic_categories=3, dirichlet_param=0.01, n_points=[5, 4],
+                                      fixed_inducing_points=True, inducing_init="grid", maxjitter=15, jitter=1e-6, device=device,
+                                      dtype=torch.float64, guide_rescale=rescale)
+        eng = model._engine_for(m.N)
+        for name in eng.PARAM_NAMES:
+            eng.view(name).copy_(m.params[name].detach().to(eng.device))
+        sc = poutine.scale(scale=1.0 / m.N)
+        svi = SVI(model=sc(model.model), guide=sc(model.guide), optim=Adam({"lr": 1e-2}), loss=Trace_ELBO())
+        g = torch.Generator().manual_seed(9)
+        for step in range(3):
+            eps = torch.randn(3, m.N, generator=g, dtype=torch.float64)
+            got = svi.step(xs=xs_w.to(device), ws=m.ws.to(device), eps=eps)
+            ref = m.step(eps)
+            assert abs(got - ref) <= LOSS_TOL_VS_TORCH * abs(ref), (rescale, step, got, ref)
+        # the predictive path scales once in the reference too (sparse_gdrf.py:161-162)
+        assert relerr(model.topic_probs(xs_w.to(device)).cpu().numpy(), m.topic_probs(xs_w).numpy()) < 1e-7
+    with pytest.raises(AssertionError):
+        model.topic_probs(xs_w.to(device) + 10.0)              # outside the world: _check_bounds (topic_model.py:191-198)

@@ -13,14 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(dtype=torch.float32, K=4, V=20, n_points=(6, 5), W=30, H=20, opt="adamw", kernel="rbf", seed=3, jitter=1e-6):
+def _build(dtype=torch.float32, K=4, V=20, n_points=(6, 5), W=30, H=20, opt="adamw", kernel="rbf", seed=3, jitter=1e-6, device="cuda:0"):
     from gdrf_amd import poutine
     from gdrf_amd.infer import OBJECTIVE_DICT, SVI
     from gdrf_amd.kernels import KERNEL_DICT
     from gdrf_amd.models import GDRF_MODEL_DICT
     from gdrf_amd.optim import OPTIMIZER_DICT
     xs_np, ws_np, _ = synth_circles(W, H, V, K, seed=seed)
-    device = "cuda:0"
     xs = torch.from_numpy(xs_np).float().to(device)                 # train_script.py:264-268
     ws = torch.from_numpy(ws_np).int().to(device)
     world = list(zip(xs.min(dim=0).values.cpu().numpy().tolist(), xs.max(dim=0).values.cpu().numpy().tolist()))
@@ -129,6 +128,45 @@ def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
     assert np.allclose(r0["losses"], ref, rtol=1e-10)                      # Philox keyed by the global row: same eps
     assert torch.equal(r0["params"], r1["params"])
     assert (r0["params"] - model._engine.params.cpu()).abs().max() < 1e-9
+
+
+def _rccl_worker(rank, world, port, tmp, dtype_name):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))   # RCCL, one GPU per rank
+    dtype = getattr(torch, dtype_name)
+    model, svi, _, xs, ws = _build(dtype=dtype, device=f"cuda:{rank}")
+    N = len(xs)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    svi.row_offset = lo
+    losses = [svi.step(xs=xs[lo:hi], ws=ws[lo:hi], subsample=False) for _ in range(3)]
+    torch.save({"losses": losses, "params": model._engine.params.cpu()}, os.path.join(tmp, f"nccl_{dtype_name}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL all-reduce of the step (one rank per GPU)")
+@pytest.mark.parametrize("dtype_name", ["float64", "float32"])
+def test_two_ranks_over_rccl_match_a_single_rank(tmp_path, dtype_name):
+    """The same sharded step as above with backend="nccl" (RCCL over xGMI), one rank per GPU: the step's single all-reduce of the
+    flat payload (red_d packed into its tail).  Skipped on one-GPU boxes; the driver's multi-GPU node runs it."""
+    import torch.multiprocessing as mp
+    port = 32600 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(2, port, str(tmp_path), dtype_name), nprocs=2, join=True)
+    dtype = getattr(torch, dtype_name)
+    model, svi, _, xs, ws = _build(dtype=dtype)
+    ref = [svi.step(xs=xs, ws=ws, subsample=False) for _ in range(3)]
+    r0 = torch.load(tmp_path / f"nccl_{dtype_name}_0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / f"nccl_{dtype_name}_1.pt", weights_only=True)
+    assert r0["losses"] == r1["losses"] and torch.equal(r0["params"], r1["params"])      # replicated epilogue: bit-identical ranks
+    tol = 1e-10 if dtype == torch.float64 else 1e-5
+    assert np.allclose(r0["losses"], ref, rtol=tol)
+    assert (r0["params"] - model._engine.params.cpu()).abs().max() < (1e-9 if dtype == torch.float64 else 1e-4)
 
 
 def _build_lz_renyi(dtype=torch.float64):
