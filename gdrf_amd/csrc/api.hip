@@ -812,7 +812,8 @@ template <typename T, typename TS> struct Impl {
         return 128 + ((size_t)2 * K * V + (size_t)rb * (K + 1) * (kreg ? 1 : 2) + (size_t)rb * (V + 1) * (wsep ? 2 : 1)) * sizeof(T);
       };
       int RB = 128;
-      bool wsep = kreg && lds_for(128, true) <= 150 * 1024;      // the counts in their own LDS rows (p evaluated once) when that keeps 128 rows per block
+      const char* wst = getenv("GDRF_ROWS_STAGE_WS");
+      bool wsep = kreg && wst && wst[0] == '1' && lds_for(128, true) <= 150 * 1024;      // A/B knob: the counts staged through LDS (measured slower)
       while (RB > 32 && lds_for(RB, wsep) > 150 * 1024) RB >>= 1;
       const size_t lds = lds_for(RB, wsep);
       if (lds > 150 * 1024)

@@ -31,7 +31,7 @@
 namespace gdrf {
 
 template <typename T> struct NTCfg {
-  static constexpr int BK = GDRF_KBYTES / (int)sizeof(T);   // 32 (f32) / 16 (f64)
+  static constexpr int BK = GDRF_KBYTES_F64 > 0 && sizeof(T) == 8 ? GDRF_KBYTES_F64 / 8 : GDRF_KBYTES / (int)sizeof(T);   // 32 (f32) / 16 or 32 (f64)
   static constexpr int VE = 16 / (int)sizeof(T);            // elements per 16-byte vector
   static constexpr int LDK = BK + VE;                       // padded LDS row: 144 bytes
   static constexpr int KG = BK / 4;                         // k indices per lane group per chunk
@@ -47,8 +47,8 @@ template <typename T> struct NTCfg {
 };
 
 // row (0..127) and k offset (elements) of the i-th vector a thread stages
-template <typename T> __device__ __forceinline__ int nt_stage_row(int i) { return (threadIdx.x >> 3) + 32 * i; }
-template <typename T> __device__ __forceinline__ int nt_stage_k() { return (threadIdx.x & 7) * NTCfg<T>::VE; }
+template <typename T> __device__ __forceinline__ int nt_stage_row(int i) { return (int)(threadIdx.x / NTCfg<T>::VPR) + (256 / NTCfg<T>::VPR) * i; }
+template <typename T> __device__ __forceinline__ int nt_stage_k() { return (int)(threadIdx.x % NTCfg<T>::VPR) * NTCfg<T>::VE; }
 
 // workgroups per CU the register allocation must leave room for (a problem may declare `static constexpr int MIN_WGS`)
 template <class P, class = void> struct NTMinWgs { static constexpr int value = 2; };

@@ -845,14 +845,15 @@ template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRow
 // =====================================================================================
 // elbo_rows: per observation: variance, reparameterised draw, softmax link, Multinomial
 // log-likelihood, both Normal site terms, and the row-local part of the backward.
-// One thread per row.  The workgroup's RB rows of counts (RB * V contiguous int32) are staged into LDS with whole-line
-// 16-byte loads and each thread then walks its own row there (row stride V + 1: conflict-free), instead of every lane
-// striding through HBM V * 4 bytes apart.  KREG: K <= GDRF_KMAX, the per-topic values of a row live in registers; otherwise
+// One thread per row.  Each lane walks its own row of counts (V int32, contiguous) straight from global memory: the lanes of a wave are
+// V * 4 bytes apart, but every lane consumes whole lines over its V iterations, so the 200 MB stream is read once (0.87 ms at the
+// headline size); staging the workgroup's rows through LDS with whole-line 16-byte loads (WSTAGE) was measured SLOWER (1.1-1.5 ms: an
+// extra pass and barrier in a kernel that lives on occupancy), it is kept for A/B runs only.  KREG: K <= GDRF_KMAX, the per-topic values of a row live in registers; otherwise
 // they are re-read from the (K, n) arrays (coalesced over the rows) and the softmax pull-back goes through LDS - any K.
 // =====================================================================================
 #define GDRF_KMAX 32
 
-template <typename T, bool KREG, bool WSEP = true>
+template <typename T, bool KREG, bool WSTAGE = false>
 __global__ __launch_bounds__(128) void elbo_rows_kernel(
     int64_t nrows, int K, int V, const Hyper* __restrict__ h,
     const T* __restrict__ qpart, int nqpart, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps,
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
   T* thS = accS + K * V;                                // [RB][K+1]
   T* pbS = thS + RB * (K + 1);                          // [RB][V+1]
   T* tbS = pbS + RB * (V + 1);                          // [RB][K+1], !KREG only
-  T* wS = tbS + (KREG ? 0 : RB * (K + 1));              // [RB][V+1] the counts, WSEP only (else they share pbS and p is evaluated twice)
+  T* wS = tbS + (KREG ? 0 : RB * (K + 1));              // [RB][V+1] the counts, WSTAGE only
   for (int e = threadIdx.x; e < K * V; e += RB) { phiS[e] = phi[e]; accS[e] = 0; }
   __syncthreads();
   const T var = (T)h->var, eta = (T)h->noise;
@@ -883,24 +884,23 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
     T* th = thS + threadIdx.x * (K + 1);
     T* pb = pbS + threadIdx.x * (V + 1);
     T* tbl = tbS + threadIdx.x * (K + 1);
-    T* const cntS = WSEP ? wS : pbS;
-    const T* wrow = cntS + threadIdx.x * (V + 1);
-    {   // counts of this block's rows -> LDS (as T): element e of the contiguous RB x V block is row e / V, taxon e % V
+    const T* wrow = wS + threadIdx.x * (V + 1);
+    if constexpr (WSTAGE) {   // counts of this block's rows -> LDS (as T) with whole-line loads
       const int64_t e0 = blk * RB * (int64_t)V;
       int64_t cnt = (nrows - blk * RB < RB ? nrows - blk * RB : (int64_t)RB) * V;
       const int32_t* src = ws + e0;
       const int head = (int)((4 - (e0 & 3)) & 3);         // elements in front of the first 16-byte aligned one
-      for (int64_t e = threadIdx.x; e < head && e < cnt; e += RB) cntS[(e / V) * (V + 1) + e % V] = (T)src[e];
+      for (int64_t e = threadIdx.x; e < head && e < cnt; e += RB) wS[(e / V) * (V + 1) + e % V] = (T)src[e];
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       const int64_t nvec = cnt > head ? (cnt - head) >> 2 : 0;
       for (int64_t q = threadIdx.x; q < nvec; q += RB) {
         const i32x4 w4 = *reinterpret_cast<const i32x4*>(src + head + 4 * q);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int64_t e = head + 4 * q + j; cntS[(e / V) * (V + 1) + e % V] = (T)w4[j]; }
+        for (int j = 0; j < 4; ++j) { const int64_t e = head + 4 * q + j; wS[(e / V) * (V + 1) + e % V] = (T)w4[j]; }
       }
-      for (int64_t e = head + 4 * nvec + threadIdx.x; e < cnt; e += RB) cntS[(e / V) * (V + 1) + e % V] = (T)src[e];
+      for (int64_t e = head + 4 * nvec + threadIdx.x; e < cnt; e += RB) wS[(e / V) * (V + 1) + e % V] = (T)src[e];
+      __syncthreads();
     }
-    __syncthreads();
     T v[KR], mu[KR], ep[KR];
     T a = 0, vd = 0;
     if (ok) {
@@ -936,17 +936,15 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
       for (int vv = 0; vv < V; ++vv) {
         T p = 0;
         for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
-        if (WSEP) pb[vv] = p;
+        pb[vv] = p;
         ps += p;
       }
       const T ips = T(1) / ps;
       T llw = 0;
       for (int vv = 0; vv < V; ++vv) {
-        T p;
-        if (WSEP) p = pb[vv];
-        else { p = 0; for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv]; }
+        const T p = pb[vv];
         const T ph = p * ips;
-        const T wv = wrow[vv];
+        const T wv = WSTAGE ? wrow[vv] : (T)ws[n * V + vv];
         const bool inr = (ph > feps) && (ph < T(1) - feps);
         const T phc = fmin(fmax(ph, feps), T(1) - feps);
         llw += wv * t_log<T>(phc);
