@@ -707,6 +707,9 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_split_cc_kernel(BwdWbarSplitA
 // k-steps per (reduction block, topic) halve that update per MFMA: 96 MFMAs, one update, one barrier per phase.  LDS: the A image
 // (this group's rows x 64 k, 32 KB) is SINGLE-buffered - its fragments live in registers for the K topic phases of a block, so the
 // next block's image is requested in the phase after they were read (K >= 2) -; B (shared, 32 KB) is double-buffered.
+// ABL (timing-only diagnostic builds, results wrong): 1 = no acc += s P update (MFMAs accumulate straight into acc), 2 = no LDS-DMA after
+// the prologue, 4 = B fragments read once per phase group (b = 0) only
+template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitArgs<SplitF16> g) {
   using SP = SplitF16;
   using CF = SplitCfg<SP>;
@@ -802,8 +805,8 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
       for (int p = 0; p < NP; ++p) fbq[0][ks][p] = *reinterpret_cast<const V8*>(Bb + (ks * NP + p) * CF::PIECE + (wc * 64) * 32 + frag);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      V8 (&fb)[2][NP] = fbq[b & 1];
-      if (b + 1 < 4) {
+      V8 (&fb)[2][NP] = fbq[(ABL & 4) ? 0 : (b & 1)];
+      if (b + 1 < 4 && !(ABL & 4)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -816,14 +819,19 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
 #pragma unroll
         for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
-          for (int a = 0; a < 4; ++a) P[a] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], (ks == 0 && t == 0) ? f32x4{0, 0, 0, 0} : P[a]);
+          for (int a = 0; a < 4; ++a) {
+            if (ABL & 1) acc[a][b] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], acc[a][b]);
+            else P[a] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], (ks == 0 && t == 0) ? f32x4{0, 0, 0, 0} : P[a]);
+          }
       // the next chunk's requests, one or two behind each column group's MFMAs (an LDS-DMA instruction stalls its wave at issue)
-      if (more) dma_b1(c + 1, b >> 1, b & 1);
-      if (more_a) { dma_a1(q + 1, b >> 1, 0, b & 1); dma_a1(q + 1, b >> 1, 1, b & 1); }
+      if (more && !(ABL & 2)) dma_b1(c + 1, b >> 1, b & 1);
+      if (more_a && !(ABL & 2)) { dma_a1(q + 1, b >> 1, 0, b & 1); dma_a1(q + 1, b >> 1, 1, b & 1); }
+      if (!(ABL & 1)) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] += s4[a][r] * P[a][r];
+          for (int r = 0; r < 4; ++r) acc[a][b][r] += s4[a][r] * P[a][r];
+      } else if (b == 3) asm volatile("" :: "v"(s4[0][0] + s4[1][1] + s4[2][2] + s4[3][3]));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -865,7 +873,11 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tile[(a2 * 16 + lg * 4 + r) * TS + b * 16 + lr] = acc[2 * h + a2][b][r];
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[2 * h + a2][b][r];
+            if (ABL) v = (fabsf(v) < 1e30f) ? v * 1e-30f : 0.0f;     // ablated builds compute garbage: keep it finite and tiny
+            tile[(a2 * 16 + lg * 4 + r) * TS + b * 16 + lr] = v;
+          }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave writes and reads: LDS is in order per wave
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
