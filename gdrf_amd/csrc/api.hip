@@ -313,7 +313,7 @@ int gdrf_set_dirichlet(gdrf_ctx* c, const double* alpha) {
   return 0;
 }
 
-// which = 0 W, 1 Wbar, 2 q, 3 loc, 4 tt, 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST
+// which = 0 W, 1 Wbar, 2 q, 3 loc, 4 tt, 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST, 17 Knm (solve precision)
 static int ws_lookup(gdrf_ctx* c, int which, void** ptr, int64_t* nelem, int* esz) {
   const int64_t mm = (int64_t)c->Mp * c->Mp, kn = (int64_t)c->K * c->ldk;
   void* p = nullptr; int64_t n = 0; int e = (int)c->esz;
@@ -327,6 +327,7 @@ static int ws_lookup(gdrf_ctx* c, int which, void** ptr, int64_t* nelem, int* es
     case 12: p = c->Bm; n = mm * c->K; break;         case 13: p = c->phi; n = (int64_t)c->K * c->V; break;
     case 14: p = c->mu; n = kn; break;                case 15: p = c->LinvT; n = mm; e = (int)c->ssz; break;
     case 16: p = c->ST; n = mm * c->K; break;
+    case 17: p = c->Knm; n = c->ncap * c->Mp; e = (int)c->ssz; break;
     default: return fail(-1, "gdrf_ws_ptr", "unknown buffer id");
   }
   *ptr = p; *nelem = n; *esz = e;
@@ -693,6 +694,16 @@ template <typename T, typename TS> struct Impl {
     int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
+    if constexpr (sizeof(TS) == 8) {
+      if (c->kind == 0 && vpr <= 256) {
+        if (c->D <= 2) hipLaunchKernelGGL((knm_rbf_f64_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, (const double*)Q(c->Zs), c->M, c->D, c->hyp,
+                                          (double*)Q(c->Knm), (int64_t)c->Mp);
+        else hipLaunchKernelGGL((knm_rbf_f64_kernel<T, GDRF_DMAX>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, (const double*)Q(c->Zs), c->M, c->D, c->hyp,
+                                (double*)Q(c->Knm), (int64_t)c->Mp);
+        LAUNCHCHK("knm_solve");
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((knm_kernel<TS, T, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, n, (const TS*)Q(c->Zs), c->M, c->D, c->kind,
                        c->hyp, Q(c->Knm), (int64_t)c->Mp);
     LAUNCHCHK("knm_solve");

@@ -26,6 +26,74 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type vzero()
 // =====================================================================================
 template <typename T> __device__ __forceinline__ T cov_fast(int kind, T r2, T var, T alpha);
 
+// 2^t in double for t <= ~1000 (0 below -1100), straight-line: 2^t = ldexp(P(t - rint t), rint t), P the degree-12 Taylor
+// polynomial of 2^r on [-1/2, 1/2] (remainder (ln2 / 2)^13 / 13! = 1.7e-16 relative).  The coefficients ln2^i / i! come from
+// constant memory, i.e. scalar registers: a Horner step is then ONE v_fma_f64 (with literal constants the compiler emits
+// v_mov_b64 + v_fmac_f64 per step, which made the K_nm kernel VALU-bound).
+__constant__ double exp2_coef[13] = {1.0, 0.6931471805599453, 0.2402265069591007, 0.055504108664821576, 0.009618129107628477, 0.0013333558146428441, 0.00015403530393381606, 1.5252733804059838e-05, 1.3215486790144305e-06, 1.0178086009239696e-07, 7.054911620801121e-09, 4.44553827187081e-10, 2.5678435993488196e-11};
+__device__ __forceinline__ double exp2_poly(double t) {
+  t = fmax(t, -1100.0);
+  const double k = __builtin_rint(t), r = t - k;             // exact: |r| <= 1/2
+  double p = exp2_coef[12];
+#pragma unroll
+  for (int i = 11; i >= 0; --i) p = fma(p, r, exp2_coef[i]);
+  return __builtin_ldexp(p, (int)k);
+}
+
+// RBF K_nm in double (the in-step solve-precision copy), its own kernel so that it does not carry the generic kernel's
+// 132 registers (3 workgroups per CU): the generic loop branches on the kernel kind per element around the library exp().
+// Straight-line form, 4 rows x 2 columns = 8 independent chains per lane: k = 2^t, t = log2 var - sum_d (a x_d - a z_d)^2
+// with the coordinates pre-scaled by a = sqrt(log2(e) / 2) / ls (exp2_poly above).  Needs ldo % 2 == 0 and ldo / 2 <= 256.
+template <typename TX, int DD, bool NT = true>
+__global__ __launch_bounds__(256, 4) void knm_rbf_f64_kernel(const TX* __restrict__ X, int64_t N, const double* __restrict__ Z, int M, int D,
+                                                          const Hyper* __restrict__ h, double* __restrict__ out, int64_t ldo) {
+  typedef double V __attribute__((ext_vector_type(2)));
+  const int vpr = (int)(ldo / 2), rpp = 256 / vpr;
+  const int rsub = (int)threadIdx.x / vpr, cv = (int)threadIdx.x % vpr, i0 = cv * 2;
+  if (rsub >= rpp) return;
+  // a workgroup owns a contiguous block of rows: addresses are a uniform base plus a 32-bit offset (the host keeps
+  // rows-per-workgroup x ldo below 2^31), and a pass writes 4 rpp adjacent rows
+  const int64_t rows_per = (N + gridDim.x - 1) / gridDim.x, rb = (int64_t)blockIdx.x * rows_per;
+  if (rb >= N) return;
+  const int nr = (int)((N - rb < rows_per) ? N - rb : rows_per);
+  double* __restrict__ ob = out + rb * ldo;
+  const TX* __restrict__ xb = X + rb * D;
+  const double a = sqrt(0.5 * 1.4426950408889634074 * h->inv_ls2), lv = log2(h->var);
+  double z[2][DD];       // coordinates beyond D are zero on both sides; a padding column sits at 1e160: t = -inf, clamped, 2^-1100 = 0
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int d = 0; d < DD; ++d) z[e][d] = (i0 + e < M) ? ((d < D) ? a * Z[(int64_t)(i0 + e) * D + d] : 0.0) : ((d == 0) ? 1e160 : 0.0);
+  const int ldo32 = (int)ldo;
+  for (int r0 = rsub; r0 < nr; r0 += 4 * rpp) {
+    double x[4][DD];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r0 + u * rpp;
+#pragma unroll
+      for (int d = 0; d < DD; ++d) x[u][d] = (rr < nr && d < D) ? a * (double)xb[rr * D + d] : 0.0;
+    }
+    V o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        double t = lv;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) { const double dd = x[u][d] - z[e][d]; t = fma(-dd, dd, t); }
+        o[u][e] = exp2_poly(t);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r0 + u * rpp;
+      if (rr < nr) {
+        V* dst = reinterpret_cast<V*>(ob + (unsigned)(rr * ldo32 + i0));
+        if (NT) __builtin_nontemporal_store(o[u], dst); else *dst = o[u];
+      }
+    }
+  }
+}
+
 // T: output / arithmetic type, TX: type of X, FAST: v_exp_f32-based exponential (roofline kernel) or exact exp
 // (the solve-precision copy of K_nm that feeds W = K_nm L^-T).  Columns M..ldo-1 of every row are written as zeros.
 template <typename T, typename TX, bool FAST, bool NT = true>

@@ -21,7 +21,7 @@ KERNEL_IDS = {"rbf": 0, "matern52": 1, "matern32": 2, "exponential": 3, "rationa
 OPT_MODES = {"adam": 0, "adamw": 1, "clippedadam": 2}
 
 _WS_IDS = dict(W=0, Wbar=1, q=2, loc=3, tt=4, vbar=5, locbar=6, asum=7, Kuu=8, L=9, Linv=10, S=11, B=12, phi=13,
-               mu=14, LinvT=15, ST=16)
+               mu=14, LinvT=15, ST=16, Knm=17)
 
 
 def _stream_ptr(device) -> int:
@@ -171,7 +171,7 @@ class Engine:
         Mp = (self.M + 31) // 32 * 32
         ldk = (self.n_cap + 3) // 4 * 4
         n = self.n_cap if n_rows is None else n_rows
-        if name in ("W", "Wbar"):
+        if name in ("W", "Wbar", "Knm"):
             return flat.view(self.n_cap, Mp)[:n, :self.M].clone()
         if name in ("q", "asum"):
             return flat[:n].clone()

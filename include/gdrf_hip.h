@@ -170,9 +170,9 @@ int gdrf_predict(gdrf_ctx* ctx, const void* X_dev, int64_t n, const void* Z_dev,
 int gdrf_chol_failed(gdrf_ctx* ctx, int* failed_host, void* stream);
 
 /* Borrowed pointers into the workspace (for parity tests): which = 0 W, 1 Wbar, 2 q, 3 loc, 4 tt,
- * 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST. */
+ * 5 vbar, 6 locbar, 7 asum, 8 Kuu, 9 L, 10 Linv, 11 S, 12 B, 13 phi, 14 mu, 15 LinvT, 16 ST, 17 the step's K_nm. */
 int gdrf_ws_ptr(gdrf_ctx* ctx, int which, void** ptr, int64_t* nelem);
-/* Element size (4 or 8 bytes) of that buffer: Kuu, L, Linv, LinvT live in the solve precision. */
+/* Element size (4 or 8 bytes) of that buffer: Kuu, L, Linv, LinvT and the step's K_nm live in the solve precision. */
 int gdrf_ws_elem_size(gdrf_ctx* ctx, int which);
 /* Device-to-device copy of the first nelem elements of that buffer into dst_dev. */
 int gdrf_ws_copy(gdrf_ctx* ctx, int which, void* dst_dev, int64_t nelem, void* stream);

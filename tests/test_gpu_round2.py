@@ -262,3 +262,26 @@ def test_non_unit_world_through_the_model_surface():
         assert relerr(model.topic_probs(xs_w.to(device)).cpu().numpy(), m.topic_probs(xs_w).numpy()) < 1e-7
     with pytest.raises(AssertionError):
         model.topic_probs(xs_w.to(device) + 10.0)              # outside the world: _check_bounds (topic_model.py:191-198)
+
+
+@pytest.mark.parametrize("lengthscale", [0.1, 0.004])
+def test_in_step_knm_in_the_solve_precision_matches_numpy_exp(lengthscale):
+    """The step's own K_nm (float64 beside float32 arrays; RBF: a straight-line 2^t polynomial instead of the library exp) against
+    numpy's exp at the same float32 inputs: round-off only, and exact zeros where the covariance underflows (lengthscale 0.004
+    puts far pairs beyond 2^-1100)."""
+    m, eps = make_oracle(kind="rbf", W=37, H=11, n_points=(6, 5), dtype=torch.float32, lengthscale=lengthscale)
+    eng = engine_from_oracle(m)
+    eng.loss_and_grads(dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng), force_level=3)
+    torch.cuda.synchronize()
+    got = eng.workspace("Knm", n_rows=m.xs.shape[0]).cpu().numpy()
+    assert got.dtype == np.float64
+    x, z = m.xs.float().double().numpy(), eng.Z.cpu().double().numpy()
+    ls = float(np.exp(np.float64(eng.view("log_lengthscale").cpu().numpy().reshape(-1)[0])))
+    var = float(np.exp(np.float64(eng.view("log_variance").cpu().numpy().reshape(-1)[0])))
+    r2 = ((x[:, None, :] - z[None, :, :]) ** 2).sum(-1) / ls ** 2
+    ref = var * np.exp(-0.5 * r2)
+    big = ref > 1e-280
+    assert np.abs(got[big] / ref[big] - 1.0).max() < 2e-12 * max(1.0, float(r2[big].max()) / 50)       # the argument's own rounding grows with r2
+    assert np.abs(got[~big]).max(initial=0.0) <= 1e-279
+    if lengthscale < 0.01:
+        assert (ref == 0).any() and (got[ref == 0] == 0).all()
