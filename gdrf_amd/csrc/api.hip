@@ -584,6 +584,12 @@ template <typename T, typename TS> struct Impl {
       if (alt && alt[0] == '1') {
         HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
         hipLaunchKernelGGL(fwd_t_split_2g_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
+      } else if (SP::NP == 2 && !(getenv("GDRF_FWDT_Q4") && getenv("GDRF_FWDT_Q4")[0] == '0')) {
+        if constexpr (SP::NP == 2) {       // 256 x 256 workgroup tiles (two-piece modes: eight operand images in 128 KB)
+          constexpr int lds4 = 8 * SplitCfg<SP>::IMG * 2 + 8 * GDRF_TILE * 4;      // + the row-sum slots
+          HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_q4_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+          hipLaunchKernelGGL(fwd_t_split_q4_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(1024), lds4, s, a);
+        }
       } else {
         HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_cc_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
         hipLaunchKernelGGL(fwd_t_split_cc_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);

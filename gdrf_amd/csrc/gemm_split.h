@@ -151,6 +151,10 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
   // it on gfx9+), and every statement that needs it sets it itself.
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a wave-uniform 64-bit base (scalar registers) and a 32-bit unsigned byte offset per lane: one address VGPR instead of two
+__device__ __forceinline__ void glds16_asm_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned long long split_stamp() {          // diagnostic builds only
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
@@ -1250,6 +1254,176 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
     const SplitLay SL{g.K};
     const float un = g.sc[SL.w() + 1] * g.sc[SL.st(bz) + 1];
     if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = rsum[tid] * (un * un);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The concurrent form on a 256 x 256 workgroup tile: FOUR wave groups (2 row tiles x 2 column tiles, 16 waves, four per SIMD).
+// Per 32-deep chunk the 512-thread form above moves 48 KB into LDS for 768 matrix-pipe cycles - 62 B/clk/CU, about twice what
+// a CU's L2 -> LDS path sustains, so its phases were as long as their DMAs (9.8 ms for 4.5 ms of MFMAs at the held clock).
+// Here both W images are read by two column groups and both S_k^T images by two row groups: 64 KB per 1536 pipe cycles.
+// The triangle is kept at 128-column granularity: column group 1 of a pair starts 128 reduction indices later than group 0
+// (S_k^T is zero above), sits those chunks out (its waves only issue their share of the DMAs) and its B image is not fetched.
+// 8 images of NP x 8 KB: two-piece modes only (128 KB).
+template <class SP>
+__global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> g) {
+  using CF = SplitCfg<SP>;
+  using E = typename SP::E;
+  using V8 = typename SP::V8;
+  constexpr int NP = SP::NP;
+  static_assert(NP == 2, "eight operand images must fit in LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = CF::IMG;
+  const int gp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int gr = gp >> 1, gc = gp & 1;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int w16 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  E* Asm = reinterpret_cast<E*>(smem);                    // [2 row groups][2 buffers][NP][128][32]
+  E* Bsm = reinterpret_cast<E*>(smem) + 4 * IMG;          // [2 column groups][2 buffers][NP][128][32]
+  const int Mp = g.Mp;
+  const int nct = (Mp + GDRF_TILE - 1) / GDRF_TILE, ncp = (nct + 1) / 2;
+  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const unsigned per_group = (unsigned)g.KG * (unsigned)g.rt8;
+  const int grp = (int)(idx / per_group);
+  const unsigned rem = idx - (unsigned)grp * per_group;
+  const int kg = min(g.KG, g.K - grp * g.KG);
+  const int64_t rt0 = 2 * ((int64_t)(rem / (unsigned)kg) * 8 + xcd);   // the pair's first row tile
+  const int bz = grp * g.KG + (int)(rem % (unsigned)kg);
+  const int64_t m0 = (rt0 + gr) * GDRF_TILE;                   // a tile past the end runs on clamped rows; its tt is never stored
+
+  const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
+  const unsigned a_lds = lds_addr(Asm), b_lds = lds_addr(Bsm);
+  // the 2 x NP x 8 requests (16 rows each) of either operand of a chunk are dealt over the 16 waves: slot s < NP of a wave is
+  // request w16 NP + s of the W images, slot NP + s the same request of the S_k^T images (skipped while that column group is idle).
+  // Sources are a wave-uniform base (row tile / reduction block, scalar) plus a per-lane 32-bit byte offset fixed for the launch.
+  unsigned a_off[NP], b_off[NP];
+#pragma unroll
+  for (int sl = 0; sl < NP; ++sl) {
+    const int rq = w16 * NP + sl, gi = rq / (8 * NP), rm = rq - gi * 8 * NP, rbk = rm & 7;
+    const int r = rbk * 16 + drow;
+    a_off[sl] = (unsigned)((((rt0 + gi) * GDRF_TILE + r < g.nrows) ? r : 0) * Mp + dq) * 2u;      // rows past the end read the tile's first row
+    b_off[sl] = (unsigned)(r * 32 + dq) * 2u;
+  }
+  auto dma1 = [&](int cp, int kA, int buf, int slot) {
+    const int sl = slot < NP ? slot : slot - NP;
+    const int rq = w16 * NP + sl, gi = rq / (8 * NP), rm = rq - gi * 8 * NP, p = rm >> 3, rbk = rm & 7;
+    if (slot < NP) {
+      int64_t tb = (rt0 + gi) * GDRF_TILE;
+      tb = tb < g.nrows ? tb : 0;
+      glds16_asm_s(g.Wh + p * g.w_stride + tb * Mp + kA, a_off[sl], a_lds + (unsigned)((((gi * 2 + buf) * NP + p) * CF::PIECE + rbk * 512) * 2));
+    } else {
+      const int ctq = 2 * cp + gi;
+      if (ctq < nct && kA >= ctq * GDRF_TILE) {
+        // a partial last column tile: its rows past Mp are never summed; they read from column 0 of the same block instead
+        const int cbase = (ctq * GDRF_TILE + rbk * 16 + 15 < Mp) ? ctq * GDRF_TILE : -(rbk * 16);
+        glds16_asm_s(g.STh + p * g.piece_stride + (((int64_t)bz * (Mp >> 5) + (kA >> 5)) * Mp + cbase) * 32, b_off[sl],
+                     b_lds + (unsigned)((((gi * 2 + buf) * NP + p) * CF::PIECE + rbk * 512) * 2));
+      }
+    }
+  };
+  // row sums of squares: one LDS slot per (row group, column group, wave column, row), behind the images; a finished column tile
+  // is folded into it by its own wave (no other writer), so the order of the additions is fixed
+  float* rsum = reinterpret_cast<float*>(smem + (size_t)8 * IMG * 2) + (gp * 2 + wc) * GDRF_TILE;
+  rsum[wr * 64 + lane] = 0.0f;                            // this wave's 64 rows (ordered before its own later updates: same wave, LDS in order)
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  const int frag = lr * 32 + ((lg ^ split_swz(lr)) << 3);
+  int buf = 0;
+#pragma unroll
+  for (int sl = 0; sl < 2 * NP; ++sl) dma1(0, 0, 0, sl);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // Every chunk issues the requests of the chunk after it (the last one re-requests itself into the idle buffers: nobody reads them),
+  // so the multiply loop has no branch around its DMAs; a group's idle chunks run in a loop of their own that never touches the
+  // accumulators (with both in one loop body hipcc kept copies of them across the branch and spilled at 128 registers).
+  auto next_chunk = [&](int cp, int kA, int& cp1, int& kA1) {
+    cp1 = cp; kA1 = kA + CF::BK;
+    if (kA1 >= Mp) {
+      if (cp + 1 < ncp) { cp1 = cp + 1; kA1 = cp1 * 2 * GDRF_TILE; } else kA1 = kA;
+    }
+  };
+#pragma unroll 1
+  for (int cp = 0; cp < ncp; ++cp) {
+    const int ct = 2 * cp + gc;
+    int kA = cp * 2 * GDRF_TILE;
+    const int k_act = (ct < nct) ? ct * GDRF_TILE : Mp;          // this group multiplies the chunks kA >= k_act
+#pragma unroll 1
+    for (; kA < k_act && kA < Mp; kA += CF::BK) {
+      int cp1, kA1;
+      next_chunk(cp, kA, cp1, kA1);
+#pragma unroll
+      for (int sl = 0; sl < 2 * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf ^= 1;
+    }
+#pragma unroll 1
+    for (; kA < Mp; kA += CF::BK) {
+      int cp1, kA1;
+      next_chunk(cp, kA, cp1, kA1);
+      const E* Ab = Asm + (gr * 2 + buf) * IMG;
+      const E* Bb = Bsm + (gc * 2 + buf) * IMG;
+      V8 fb[NP][4];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        __builtin_amdgcn_sched_barrier(0);                       // keeps hipcc from hoisting the later row blocks' reads
+        V8 fa[NP];                                               // one row block at a time: the SIMD's other three waves cover the read
+#pragma unroll
+        for (int p = 0; p < NP; ++p) fa[p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
+#pragma unroll
+        for (int t = 0; t < SP::NPROD; ++t)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = SP::mma(fa[SP::pa(t)], fb[SP::pb(t)][b], acc[a][b]);
+        if (a < 2) {                                             // the next chunk's requests behind the first two MFMA groups
+#pragma unroll
+          for (int sl = a * NP; sl < (a + 1) * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of the next chunk have landed (they had the whole phase)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf ^= 1;
+    }
+    if (ct < nct) {                                             // fold the finished column tile into the row sums, restart the accumulators
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool cok = ct * GDRF_TILE + wc * 64 + b * 16 + lr < Mp;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][r] = cok ? acc[a][b][r] * acc[a][b][r] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = group16_sum((acc[a][0][r] + acc[a][1][r]) + (acc[a][2][r] + acc[a][3][r]));
+          if (lr == 0) rsum[wr * 64 + a * 16 + lg * 4 + r] += v;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+      }
+    }
+  }
+  // the four partial sums of a row (2 column groups x 2 wave columns), added in a fixed order
+  __syncthreads();
+  if (gc == 0 && tid < GDRF_TILE) {
+    const float* q = reinterpret_cast<const float*>(smem + (size_t)8 * IMG * 2) + (gr * 2) * 2 * GDRF_TILE + tid;
+    const float v = (q[0] + q[GDRF_TILE]) + (q[2 * GDRF_TILE] + q[3 * GDRF_TILE]);
+    const int64_t m = m0 + tid;
+    const SplitLay SL{g.K};
+    const float un = g.sc[SL.w() + 1] * g.sc[SL.st(bz) + 1];
+    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = v * (un * un);
   }
 }
 
