@@ -587,8 +587,11 @@ template <typename T, typename TS> struct Impl {
       } else if (SP::NP == 2 && !(getenv("GDRF_FWDT_Q4") && getenv("GDRF_FWDT_Q4")[0] == '0')) {
         if constexpr (SP::NP == 2) {       // 256 x 256 workgroup tiles (two-piece modes: eight operand images in 128 KB)
           constexpr int lds4 = 8 * SplitCfg<SP>::IMG * 2 + 8 * GDRF_TILE * 4;      // + the row-sum slots
-          HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_q4_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
-          hipLaunchKernelGGL(fwd_t_split_q4_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(1024), lds4, s, a);
+          static const int var = getenv("GDRF_Q4_VAR") ? atoi(getenv("GDRF_Q4_VAR")) : 1;      // A/B knob; 1 (requests first) measured best
+#define GDRF_Q4(X) { HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_q4_kernel<SP, X>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4)); \
+                     hipLaunchKernelGGL((fwd_t_split_q4_kernel<SP, X>), dim3((unsigned)(8 * K * rt8)), dim3(1024), lds4, s, a); }
+          if (var == 1) GDRF_Q4(1) else if (var == 2) GDRF_Q4(2) else if (var == 3) GDRF_Q4(3) else GDRF_Q4(0)
+#undef GDRF_Q4
         }
       } else {
         HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_cc_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));

@@ -1265,7 +1265,9 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
 // The triangle is kept at 128-column granularity: column group 1 of a pair starts 128 reduction indices later than group 0
 // (S_k^T is zero above), sits those chunks out (its waves only issue their share of the DMAs) and its B image is not fetched.
 // 8 images of NP x 8 KB: two-piece modes only (128 KB).
-template <class SP>
+// VAR (A/B knob): bit 0 = the next chunk's requests at the top of the phase instead of behind the first two MFMA groups (8.8 vs 9.0 ms),
+// bit 1 = without the scheduling barrier per row block (9.2 ms)
+template <class SP, int VAR = 0>
 __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> g) {
   using CF = SplitCfg<SP>;
   using E = typename SP::E;
@@ -1368,6 +1370,10 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
       next_chunk(cp, kA, cp1, kA1);
       const E* Ab = Asm + (gr * 2 + buf) * IMG;
       const E* Bb = Bsm + (gc * 2 + buf) * IMG;
+      if (VAR & 1) {
+#pragma unroll
+        for (int sl = 0; sl < 2 * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
+      }
       V8 fb[NP][4];
 #pragma unroll
       for (int p = 0; p < NP; ++p)
@@ -1375,7 +1381,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
         for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        __builtin_amdgcn_sched_barrier(0);                       // keeps hipcc from hoisting the later row blocks' reads
+        if (!(VAR & 2)) __builtin_amdgcn_sched_barrier(0);       // keeps hipcc from hoisting the later row blocks' reads
         V8 fa[NP];                                               // one row block at a time: the SIMD's other three waves cover the read
 #pragma unroll
         for (int p = 0; p < NP; ++p) fa[p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
@@ -1383,7 +1389,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
         for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
           for (int b = 0; b < 4; ++b) acc[a][b] = SP::mma(fa[SP::pa(t)], fb[SP::pb(t)][b], acc[a][b]);
-        if (a < 2) {                                             // the next chunk's requests behind the first two MFMA groups
+        if (a < 2 && !(VAR & 1)) {                               // the next chunk's requests behind the first two MFMA groups
 #pragma unroll
           for (int sl = a * NP; sl < (a + 1) * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
         }
