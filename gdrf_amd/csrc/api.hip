@@ -48,7 +48,8 @@ struct gdrf_ctx {
   int nt;                     // 128-wide tiles over Mp
   int nsplit_cap;
   // solve precision, M x M (ld Mp)
-  void *Kuu, *Lw, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *Zs, *GTs;
+  void *mmslab;               // [8][Mp][Mp] solve precision: split-K slabs of the single M x M products
+  void *Kuu, *Lw, *Lo, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *Zs, *GTs;      // Lo: the panel-wise factorisation's output (Lw is its work matrix)
   void *Knm;                  // [ncap][Mp] K_nm in the solve precision (forward A operand, backward epilogue)
   // probe (N-side precision) scratch, only when T != TS
   void *pK, *pL;
@@ -235,7 +236,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   };
   int rc = 0;
 #define AL(ptr, bytes) if ((rc = A((void**)&(ptr), (bytes)))) { gdrf_ctx_destroy(c); return rc; }
-  AL(c->Kuu, mms) AL(c->Lw, mms) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
+  AL(c->Kuu, mms) AL(c->Lw, mms) AL(c->Lo, mms) AL(c->mmslab, 8 * mms) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
   AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->ssz)
   AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
   AL(c->Cf, (size_t)K * M * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
@@ -448,7 +449,20 @@ template <typename T, typename TS> struct Impl {
   template <typename E>
   static int mm_nt(gdrf_ctx* c, const E* A, int64_t abs_, const E* Bt, int64_t bbs, E* Cm, int64_t cbs, E alpha, int batch,
                    hipStream_t s) {
-    MMProb<E> p{{}, {}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha};
+    // a single M x M product is 16 workgroups of the NT core (45 us at M = 512 in double, four of them in a row in every step's
+    // Cholesky backward): split its reduction over 8 slices into slabs and add them (in double, fixed order)
+    static const bool splitk = !(getenv("GDRF_MM_SPLITK") && getenv("GDRF_MM_SPLITK")[0] == '0');
+    const int S = 8, kw = c->Mp / S;
+    if (batch == 1 && splitk && c->mmslab && c->Mp >= 256 && c->Mp % S == 0 && kw % NTCfg<E>::BK == 0) {
+      const int64_t mm = (int64_t)c->Mp * c->Mp;
+      MMProb<E> p{{}, {}, {}, A, 0, Bt, 0, (E*)c->mmslab, mm, c->Mp, alpha, kw};
+      dim3 grid(c->nt * nct<E>(c), S);
+      hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
+      hipLaunchKernelGGL(reduce_slabs_kernel<E>, dim3((c->Mp + 255) / 256, c->Mp, 1), dim3(256), 0, s, (const E*)c->mmslab, S, 1, c->Mp, 0, Cm, GDRF_TILE / 2);
+      LAUNCHCHK("mm_nt split-K");
+      return 0;
+    }
+    MMProb<E> p{{}, {}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha, 0};
     dim3 grid(c->nt * nct<E>(c), batch);
     hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");
@@ -494,10 +508,21 @@ template <typename T, typename TS> struct Impl {
       HIPCHK(hipMemsetAsync(c->flag, 0, 32, f));
       hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
       HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, f));
-      if (chol_lds_bytes<TS>(M) > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<TS>(M)));
-      hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), f, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
-      hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
+      static const bool panelwise = !(getenv("GDRF_CHOL_PANEL") && getenv("GDRF_CHOL_PANEL")[0] == '0');    // A/B knob: 0 = the single-workgroup kernel
+      if (panelwise) {
+        // one launch per 32-column panel, one small workgroup per trailing tile (kernels_mm.h: chol_panel_kernel)
+        const int nt = (M + 31) / 32;
+        for (int k = 0; k < nt; ++k) {
+          const int n = nt - k - 1, wgs = n > 0 ? n * (n + 1) / 2 : 1;
+          hipLaunchKernelGGL(chol_panel_kernel<TS>, dim3((unsigned)wgs), dim3(128), 0, f, Q(c->Lw), Q(c->Lo), M, Mp, k, c->flag);
+        }
+        hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lo), M, Mp, Q(c->L), Q(c->LT));
+      } else {
+        if (chol_lds_bytes<TS>(M) > 48 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<TS>(M)));
+        hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), f, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
+        hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
+      }
       hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, f, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
       hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(256), 0, f, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
                          Q(c->LinvT));

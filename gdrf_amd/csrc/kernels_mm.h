@@ -301,6 +301,184 @@ template <typename T> inline size_t chol_lds_bytes(int) {
   return (32 * ldp + 2 * 32 * 33 + 32) * sizeof(T);
 }
 
+// ---- tile Cholesky, ONE LAUNCH PER 32-COLUMN PANEL (right-looking), for the factorisation on the step's critical path.
+// chol_kernel above is one workgroup for the whole matrix: its panel update runs at the matrix rate of a single CU, its 32 x 32
+// diagonal factor costs ~1250 cycles per pivot (one LDS all-gather of the scaled column per pivot) and the rows below are LDS-fed
+// substitutions: 0.80 ms at M = 512 in double, the fixed cost of every step.  Here launch k factors panel k and applies it to the
+// whole trailing matrix with one 2-wave workgroup per trailing tile (i, j), k < j <= i; nothing inside a launch depends on another
+// workgroup (the launch boundary is the only synchronisation), because every workgroup REDOES the small serial part itself:
+//   wave 0 factors the 64 x 32 panel [A(k,k); A(i,k)], wave 1 the panel [A(k,k); A(j,k)] - the diagonal tile's factor comes out
+//   of both, L(i,k) and L(j,k) are the lower halves - then the two waves apply A(i,j) -= L(i,k) L(j,k)^T.
+// A panel lives in the accumulator layout of the 16x16x4 matrix instruction and is factored FOUR pivots at a time: the four
+// columns go through LDS once; every lane factors the 4 x 4 diagonal block redundantly (the only serial chain: 4 reciprocal
+// square roots), solves its own rows against it, and the rank-4 update of the columns to the right is <= 7 MFMAs.  8 such steps
+// per launch instead of 32 all-gathers.  L(., k) is written to a separate matrix (other workgroups of the launch still read the
+// unfactored column k), by the workgroups of trailing column k + 1; diagonal tiles are kept fully symmetric.
+// A pivot <= 0 (or NaN) sets *flag and is replaced by 1, as in chol_kernel.
+template <typename T> __device__ __forceinline__ void chol_pivot(T d, T& piv, T& rp) { piv = t_sqrt<T>(d); rp = T(1) / piv; }
+template <> __device__ __forceinline__ void chol_pivot<double>(double d, double& piv, double& rp) {
+  double y = __builtin_amdgcn_rsq(d);                        // one seed, Newton steps: the library sqrt + divide is ~45 dependent instructions
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  double p0 = d * y;
+  p0 = p0 + 0.5 * y * (d - p0 * p0);
+  piv = p0; rp = y + y * (1.0 - p0 * y);
+}
+template <typename T>
+__global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* __restrict__ Lout, int M, int ld, int k, int* __restrict__ flag) {
+  using MM = Mfma<T>;
+  using acc_t = typename MM::acc_t;
+  constexpr int LS = 34;                                     // row stride of the L tiles in LDS (elements)
+  __shared__ __attribute__((aligned(16))) T Pn[2][64][4];    // per wave: the four panel columns of the current step
+  __shared__ __attribute__((aligned(16))) T Ls[2][32][LS];   // L(i,k), L(j,k)
+  __shared__ __attribute__((aligned(16))) T Ld[2][32][LS];   // L(k,k) (each wave's own copy: identical values)
+  const int nt = (M + 31) / 32, n = nt - k - 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  int i = k, j = k;
+  if (n > 0) {                                               // trailing tiles, column by column
+    int b = blockIdx.x, jj = 0;
+    while (b >= n - jj) { b -= n - jj; ++jj; }
+    j = k + 1 + jj; i = j + b;
+  }
+  const bool last = n == 0;
+  const int t = (w == 0) ? i : j;
+  auto ld_elem = [&](int gr, int gc) -> T {
+    return (gr < M && gc < M) ? A[(int64_t)gr * ld + gc] : ((gr == gc) ? T(1) : T(0));
+  };
+  // the trailing tile's rows 16 w .. 16 w + 15 (both column halves), fetched up front
+  acc_t u[2];
+  if (!last) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[cb][r] = ld_elem(32 * i + 16 * w + MM::crow(lane, r), 32 * j + 16 * cb + lr);
+  }
+  // the panel: row blocks 0, 1 = A(k,k), 2, 3 = A(t,k); the strictly upper tile (0, 1) is never needed
+  acc_t c[4][2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = (rb < 2 ? 32 * k + 16 * rb : 32 * t + 16 * (rb - 2)) + MM::crow(lane, r);
+        c[rb][cb][r] = (rb == 0 && cb == 1) ? T(0) : ld_elem(gr, 32 * k + 16 * cb + lr);
+      }
+  typedef T V2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int j0 = 4 * s, cb0 = s >> 2;
+    // (1) the step's four columns -> LDS (16 lanes hold them)
+    if ((lr >> 2) == (s & 3)) {
+      const int q = lr & 3;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pn[w][16 * rb + MM::crow(lane, r)][q] = c[rb][cb0][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // (2) the 4 x 4 diagonal block (lower part) and this lane's four rows (row 16 rb + lr of every row block)
+    T d[4][4], x[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const V2 lo = *reinterpret_cast<const V2*>(&Pn[w][j0 + q][0]), hi = *reinterpret_cast<const V2*>(&Pn[w][j0 + q][2]);
+      d[q][0] = lo[0]; d[q][1] = lo[1]; d[q][2] = hi[0]; d[q][3] = hi[1];
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const V2 lo = *reinterpret_cast<const V2*>(&Pn[w][16 * rb + lr][0]), hi = *reinterpret_cast<const V2*>(&Pn[w][16 * rb + lr][2]);
+      x[rb][0] = lo[0]; x[rb][1] = lo[1]; x[rb][2] = hi[0]; x[rb][3] = hi[1];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                         // all reads done before the next step's columns overwrite Pn
+    // (3) factor the block: l[q][p], p <= q; ri[q] = 1 / l[q][q]
+    T l[4][4], ri[4];
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      T dq = d[q][q];
+#pragma unroll
+      for (int p = 0; p < q; ++p) dq -= l[q][p] * l[q][p];
+      if (!(dq > T(0))) { bad = bad || (32 * k + j0 + q < M); dq = T(1); }
+      chol_pivot<T>(dq, l[q][q], ri[q]);
+#pragma unroll
+      for (int q2 = q + 1; q2 < 4; ++q2) {
+        T v = d[q2][q];
+#pragma unroll
+        for (int p = 0; p < q; ++p) v -= l[q2][p] * l[q][p];
+        l[q2][q] = v * ri[q];
+      }
+    }
+    if (bad && lane == 0) *flag = 1;
+    // (4) this lane's rows against the block: x L44^T = u.  Rows of the diagonal tile above the block are finished (0), rows inside
+    //     it are the block's own rows (exactly l, zero right of the diagonal)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T v = x[rb][q];
+#pragma unroll
+        for (int p = 0; p < q; ++p) v -= x[rb][p] * l[q][p];
+        x[rb][q] = v * ri[q];
+      }
+      if (rb < 2) {
+        const int rel = 16 * rb + lr - j0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[rb][q] = (rel < q) ? T(0) : ((rel == q) ? l[q][q] : x[rb][q]);
+      }
+    }
+    // the matrix-instruction operand of row 16 rb + lr: column lg of the four
+    T op[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) op[rb] = (lg == 0) ? x[rb][0] : ((lg == 1) ? x[rb][1] : ((lg == 2) ? x[rb][2] : x[rb][3]));
+    Ld[w][lr][j0 + lg] = op[0];
+    Ld[w][16 + lr][j0 + lg] = op[1];
+    Ls[w][lr][j0 + lg] = op[2];
+    Ls[w][16 + lr][j0 + lg] = op[3];
+    // (5) rank-4 update of the columns from this block on (the block's own columns become ~0 and are not read again)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        if (cb < cb0 || (rb == 0 && (cb == 1 || s >= 4)) ) continue;
+        c[rb][cb] = MM::mma(-op[rb], op[cb], c[rb][cb]);
+      }
+  }
+  __syncthreads();
+  if (!last) {
+    // A(i,j) -= L(i,k) L(j,k)^T: this wave's 16 rows
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const T a = -Ls[0][16 * w + lr][4 * s + lg];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) u[cb] = MM::mma(a, Ls[1][16 * cb + lr][4 * s + lg], u[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = 32 * i + 16 * w + MM::crow(lane, r), gc = 32 * j + 16 * cb + lr;
+        if (gr < ld && gc < ld) A[(int64_t)gr * ld + gc] = u[cb][r];
+      }
+  }
+  // L(i,k) by the workgroups of the first trailing column, L(k,k) by the first of them (or by the last launch's only workgroup)
+  const T (*src)[LS] = nullptr; int gi = 0;
+  if (last) { if (w == 0) { src = Ld[0]; gi = k; } }
+  else if (j == k + 1) {
+    if (w == 0) { src = Ls[0]; gi = i; }
+    else if (i == k + 1) { src = Ld[1]; gi = k; }
+  }
+  if (src) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = it * 64 + lane, r = e >> 5, q = e & 31;
+      const int gr = 32 * gi + r, gc = 32 * k + q;
+      if (gr < ld && gc < ld) Lout[(int64_t)gr * ld + gc] = src[r][q];
+    }
+  }
+}
+
 // nlev copies of K (no jitter) with jitters[lev] added to the diagonal of copy lev
 struct JitterLevels { double v[8]; };
 template <typename T>
@@ -459,11 +637,14 @@ template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   const T* Bt; int64_t b_bs;
   T* C; int64_t c_bs;
   int Mp; T alpha;
+  int kw;                          // > 0: split-K - "batch" bz is a slice [bz kw, (bz + 1) kw) of the reduction (a_bs = b_bs = 0, C = slabs)
   struct ACtx { int64_t m0; }; struct ECtx {};
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
-  __device__ __forceinline__ void krange(int64_t, int, int, int& kb, int& ke) const { kb = 0; ke = Mp; }
+  __device__ __forceinline__ void krange(int64_t, int, int bz, int& kb, int& ke) const {
+    if (kw > 0) { kb = bz * kw; ke = (kb + kw < Mp) ? kb + kw : Mp; } else { kb = 0; ke = Mp; }
+  }
   __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const { c.m0 = m0; }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
   __device__ __forceinline__ V zero() const { V z; for (int e = 0; e < Vec16<T>::N; ++e) z[e] = 0; return z; }
