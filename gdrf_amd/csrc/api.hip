@@ -508,23 +508,25 @@ template <typename T, typename TS> struct Impl {
       HIPCHK(hipMemsetAsync(c->flag, 0, 32, f));
       hipLaunchKernelGGL(kuu_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp, jitter, Q(c->Kuu));
       HIPCHK(hipMemcpyAsync(c->Lw, c->Kuu, (size_t)Mp * Mp * sizeof(TS), hipMemcpyDeviceToDevice, f));
+      bool have_dinv = false;
       static const bool panelwise = !(getenv("GDRF_CHOL_PANEL") && getenv("GDRF_CHOL_PANEL")[0] == '0');    // A/B knob: 0 = the single-workgroup kernel
       if (panelwise) {
         // one launch per 32-column panel, one small workgroup per trailing tile (kernels_mm.h: chol_panel_kernel)
         const int nt = (M + 31) / 32;
         for (int k = 0; k < nt; ++k) {
           const int n = nt - k - 1, wgs = n > 0 ? n * (n + 1) / 2 : 1;
-          hipLaunchKernelGGL(chol_panel_kernel<TS>, dim3((unsigned)wgs), dim3(128), 0, f, Q(c->Lw), Q(c->Lo), M, Mp, k, c->flag);
+          hipLaunchKernelGGL(chol_panel_kernel<TS>, dim3((unsigned)wgs), dim3(128), 0, f, Q(c->Lw), Q(c->Lo), Q(c->Dinv), M, Mp, k, c->flag);
         }
         hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lo), M, Mp, Q(c->L), Q(c->LT));
+        have_dinv = true;            // the inverses of the diagonal blocks came out of the panel launches
       } else {
         if (chol_lds_bytes<TS>(M) > 48 * 1024)
           HIPCHK(hipFuncSetAttribute((const void*)chol_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes<TS>(M)));
         hipLaunchKernelGGL(chol_kernel<TS>, dim3(1), dim3(1024), chol_lds_bytes<TS>(M), f, Q(c->Lw), M, Mp, c->flag, (int64_t)0);
         hipLaunchKernelGGL(finalize_l_kernel<TS>, g2, dim3(256), 0, f, (const TS*)Q(c->Lw), M, Mp, Q(c->L), Q(c->LT));
       }
-      hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, f, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
-      hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(256), 0, f, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
+      if (!have_dinv) hipLaunchKernelGGL(trinv_diag_kernel<TS>, dim3(Mp / 32), dim3(64), 0, f, (const TS*)Q(c->L), M, Mp, Q(c->Dinv));
+      hipLaunchKernelGGL(trinv_cols_kernel<TS>, dim3(Mp / 32), dim3(1024), 0, f, (const TS*)Q(c->L), (const TS*)Q(c->Dinv), M, Mp, Q(c->Linv),
                          Q(c->LinvT));
     }
     HIPCHK(hipEventRecord(c->ev_fact, f));

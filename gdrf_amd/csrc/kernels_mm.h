@@ -317,15 +317,16 @@ template <typename T> inline size_t chol_lds_bytes(int) {
 // A pivot <= 0 (or NaN) sets *flag and is replaced by 1, as in chol_kernel.
 template <typename T> __device__ __forceinline__ void chol_pivot(T d, T& piv, T& rp) { piv = t_sqrt<T>(d); rp = T(1) / piv; }
 template <> __device__ __forceinline__ void chol_pivot<double>(double d, double& piv, double& rp) {
-  double y = __builtin_amdgcn_rsq(d);                        // one seed, Newton steps: the library sqrt + divide is ~45 dependent instructions
-  y = y * (1.5 - 0.5 * d * y * y);
+  // one v_rsq_f64 seed (>= 2^-23 relative) and ONE Newton step on it (>= 2^-45); the square root and the reciprocal each take their own
+  // correction from there, which squares the error again (the library sqrt + divide is ~45 dependent instructions on the serial chain)
+  double y = __builtin_amdgcn_rsq(d);
   y = y * (1.5 - 0.5 * d * y * y);
   double p0 = d * y;
   p0 = p0 + 0.5 * y * (d - p0 * p0);
   piv = p0; rp = y + y * (1.0 - p0 * y);
 }
 template <typename T>
-__global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* __restrict__ Lout, int M, int ld, int k, int* __restrict__ flag) {
+__global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* __restrict__ Lout, T* __restrict__ Dinv, int M, int ld, int k, int* __restrict__ flag) {
   using MM = Mfma<T>;
   using acc_t = typename MM::acc_t;
   constexpr int LS = 34;                                     // row stride of the L tiles in LDS (elements)
@@ -342,6 +343,9 @@ __global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* _
   }
   const bool last = n == 0;
   const int t = (w == 0) ? i : j;
+  // In the workgroup that stores L(k,k) wave 1 would repeat wave 0's panel (i == j).  It factors [A(k,k); 1] instead: the rows below
+  // come out as 1 L(k,k)^-T, the transposed inverse of the diagonal block, which the explicit inverse of L needs (trinv_cols_kernel)
+  const bool inv_duty = w == 1 && (last || (i == k + 1 && j == k + 1));
   auto ld_elem = [&](int gr, int gc) -> T {
     return (gr < M && gc < M) ? A[(int64_t)gr * ld + gc] : ((gr == gc) ? T(1) : T(0));
   };
@@ -362,7 +366,8 @@ __global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* _
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gr = (rb < 2 ? 32 * k + 16 * rb : 32 * t + 16 * (rb - 2)) + MM::crow(lane, r);
-        c[rb][cb][r] = (rb == 0 && cb == 1) ? T(0) : ld_elem(gr, 32 * k + 16 * cb + lr);
+        if (rb >= 2 && inv_duty) c[rb][cb][r] = (16 * (rb - 2) + MM::crow(lane, r) == 16 * cb + lr) ? T(1) : T(0);
+        else c[rb][cb][r] = (rb == 0 && cb == 1) ? T(0) : ld_elem(gr, 32 * k + 16 * cb + lr);
       }
   typedef T V2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -448,11 +453,12 @@ __global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* _
   __syncthreads();
   if (!last) {
     // A(i,j) -= L(i,k) L(j,k)^T: this wave's 16 rows
+    const int bsel = (i == j) ? 0 : 1;                        // (wave 1 of a diagonal tile may have been on inverse duty)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const T a = -Ls[0][16 * w + lr][4 * s + lg];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) u[cb] = MM::mma(a, Ls[1][16 * cb + lr][4 * s + lg], u[cb]);
+      for (int cb = 0; cb < 2; ++cb) u[cb] = MM::mma(a, Ls[bsel][16 * cb + lr][4 * s + lg], u[cb]);
     }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -475,6 +481,13 @@ __global__ __launch_bounds__(128) void chol_panel_kernel(T* __restrict__ A, T* _
       const int e = it * 64 + lane, r = e >> 5, q = e & 31;
       const int gr = 32 * gi + r, gc = 32 * k + q;
       if (gr < ld && gc < ld) Lout[(int64_t)gr * ld + gc] = src[r][q];
+    }
+  }
+  if (inv_duty && Dinv) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = it * 64 + lane, r = e >> 5, q = e & 31;
+      Dinv[(int64_t)k * 1024 + e] = (q <= r) ? Ls[1][q][r] : T(0);
     }
   }
 }
@@ -536,14 +549,18 @@ __global__ __launch_bounds__(64) void trinv_diag_kernel(const T* __restrict__ L,
 // product with Dinv[J] needs the sum turned from the accumulator layout into a left operand, through one 32x32 LDS tile.
 // (History: the scalar column form - every thread 32 LDS-fed FMAs per tile product - was LDS-bound, 310-335 us at M = 512 f64;
 // the MFMA column form with L as the left operand, 32-byte strided segments, 190 us.)
+// 16 waves: wave = (slice of the P sum, 16 x 16 quadrant).  The serial chain is the J loop (up to Mp / 32 - 1 dependent steps per block
+// row); with one wave per quadrant a step summed up to 15 tile products one after the other (137 us at M = 512 in double, behind
+// the 0.23 ms panel-wise factorisation).  The four slices' partial sums meet in LDS and are added in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(256) void trinv_cols_kernel(const T* __restrict__ L, const T* __restrict__ Dinv, int M, int Mp,
-                                                        T* __restrict__ X, T* __restrict__ XT) {
+__global__ __launch_bounds__(1024) void trinv_cols_kernel(const T* __restrict__ L, const T* __restrict__ Dinv, int M, int Mp,
+                                                         T* __restrict__ X, T* __restrict__ XT) {
   using MM = Mfma<T>;
   using acc_t = typename MM::acc_t;
-  __shared__ T Sx[32][33];
+  __shared__ T Sp[4][32][33];
   const int I = blockIdx.x, nb = Mp / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w16 = tid >> 6, wave = w16 & 3, sl = w16 >> 2;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
   auto put = [&](int J, int r, int c, T v) {
     const int gi = I * 32 + r, gj = J * 32 + c;
     if (gi >= M || gj >= M) v = 0;
@@ -552,20 +569,21 @@ __global__ __launch_bounds__(256) void trinv_cols_kernel(const T* __restrict__ L
   };
   // blocks right of the diagonal are zero
   for (int J = I + 1; J < nb; ++J)
-    for (int e = tid; e < 1024; e += 256) put(J, e >> 5, e & 31, T(0));
-  for (int e = tid; e < 1024; e += 256) put(I, e >> 5, e & 31, Dinv[(int64_t)I * 1024 + e]);
+    for (int e = tid; e < 1024; e += 1024) put(J, e >> 5, e & 31, T(0));
+  for (int e = tid; e < 1024; e += 1024) put(I, e >> 5, e & 31, Dinv[(int64_t)I * 1024 + e]);
   __threadfence_block();
   __syncthreads();
-  constexpr int PB = 4;
+  constexpr int PB = 2;
   const T* xt = XT + (int64_t)lg * Mp + I * 32 + wr * 16 + lr;         // + (P*32 + 4*kk)*Mp          : left fragment element [row lr][k lg] = X[I][P][row][k]
   const T* lp = L + (int64_t)lg * Mp + wc * 16 + lr;                   // + (P*32 + 4*kk)*Mp + J*32   : right fragment element [k lg][col lr]
   for (int J = I - 1; J >= 0; --J) {
     acc_t acc = acc_t{0, 0, 0, 0};
-    for (int P0 = J + 1; P0 <= I; P0 += PB) {
+    // slice sl takes P = J + 1 + sl, + 4, ... in pairs
+    for (int P0 = J + 1 + sl; P0 <= I; P0 += 4 * PB) {
       T a[PB][8], b[PB][8];
 #pragma unroll
       for (int u = 0; u < PB; ++u) {
-        const int P = (P0 + u <= I) ? P0 + u : P0;                      // clamped: surplus loads repeat a valid tile and are not used
+        const int P = (P0 + 4 * u <= I) ? P0 + 4 * u : P0;              // clamped: surplus loads repeat a valid tile and are not used
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           a[u][kk] = xt[(int64_t)(P * 32 + 4 * kk) * Mp];
@@ -574,20 +592,27 @@ __global__ __launch_bounds__(256) void trinv_cols_kernel(const T* __restrict__ L
       }
 #pragma unroll
       for (int u = 0; u < PB; ++u)
-        if (P0 + u <= I) {
+        if (P0 + 4 * u <= I) {
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) acc = MM::mma(a[u][kk], b[u][kk], acc);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Sx[wr * 16 + MM::crow(lane, r)][wc * 16 + lr] = acc[r];
+    for (int r = 0; r < 4; ++r) Sp[sl][wr * 16 + MM::crow(lane, r)][wc * 16 + lr] = acc[r];
     __syncthreads();
-    acc_t o = acc_t{0, 0, 0, 0};
-    const T* dj = Dinv + (int64_t)J * 1024 + lg * 32 + wc * 16 + lr;    // [k lg][col lr]
+    if (sl == 0) {
+      // left operand of the product with Dinv[J]: the sum of the four slices, element [row lr][k 4 kk + lg]
+      acc_t o = acc_t{0, 0, 0, 0};
+      const T* dj = Dinv + (int64_t)J * 1024 + lg * 32 + wc * 16 + lr;    // [k lg][col lr]
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) o = MM::mma(Sx[wr * 16 + lr][4 * kk + lg], dj[4 * kk * 32], o);
+      for (int kk = 0; kk < 8; ++kk) {
+        const int rr = wr * 16 + lr, cc = 4 * kk + lg;
+        const T sx = (Sp[0][rr][cc] + Sp[1][rr][cc]) + (Sp[2][rr][cc] + Sp[3][rr][cc]);
+        o = MM::mma(sx, dj[4 * kk * 32], o);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) put(J, wr * 16 + MM::crow(lane, r), wc * 16 + lr, -o[r]);
+      for (int r = 0; r < 4; ++r) put(J, wr * 16 + MM::crow(lane, r), wc * 16 + lr, -o[r]);
+    }
     __threadfence_block();
     __syncthreads();
   }

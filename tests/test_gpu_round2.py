@@ -285,3 +285,24 @@ def test_in_step_knm_in_the_solve_precision_matches_numpy_exp(lengthscale):
     assert np.abs(got[~big]).max(initial=0.0) <= 1e-279
     if lengthscale < 0.01:
         assert (ref == 0).any() and (got[ref == 0] == 0).all()
+
+
+@pytest.mark.parametrize("npts", [(32, 16), (13, 11)])
+def test_panelwise_cholesky_backward_error_and_block_inverse(npts):
+    """The factorisation on the step's critical path (one launch per 32-column panel, pivots from a v_rsq_f64 seed) at the headline's
+    M = 512 and at a ragged M = 143: L L^T reproduces K_uu to double round-off (a pivot only good to 2^-45 would show as 1e-13),
+    L matches numpy's factor of the same matrix, and Linv L = 1."""
+    m, _ = make_oracle(kind="rbf", W=16, H=9, n_points=npts, dtype=torch.float64, jitter=1e-6, lengthscale=0.1)
+    eng = engine_from_oracle(m)
+    eng.factorize()
+    K = eng.workspace("Kuu").cpu().numpy()
+    L = eng.workspace("L").cpu().numpy()
+    Li = eng.workspace("Linv").cpu().numpy()
+    assert np.abs(np.triu(L, 1)).max() == 0.0
+    res = np.abs(L @ L.T - K).max() / np.abs(K).max()
+    ref = np.linalg.cholesky(K)
+    res_ref = np.abs(ref @ ref.T - K).max() / np.abs(K).max()
+    print(f"M={m.M}: backward error {res:.2e} (numpy {res_ref:.2e}), |L - numpy| / |L| {np.abs(L - ref).max() / np.abs(ref).max():.2e}")
+    assert res < 4e-15 and res < 8 * res_ref + 1e-16
+    assert np.abs(Li @ L - np.eye(m.M)).max() < 1e-7                    # forward error of the inverse: condition-number bound, not round-off
+    assert relerr(L, ref) < 1e-8
