@@ -36,6 +36,8 @@ SIGNATURES = {
     "gdrf_ll_const": (_int, [_vp, _vp, _i64, C.POINTER(_dbl), _vp]),
     "gdrf_ll_const_dev": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "gdrf_probe": (_int, [_vp, _vp, _vp, C.POINTER(_dbl), _int, C.POINTER(_int), _vp]),
+    "gdrf_probe_launch": (_int, [_vp, _vp, _vp, C.POINTER(_dbl), _int, _vp]),
+    "gdrf_probe_read": (_int, [_vp, _int, C.POINTER(_int), _vp]),
     "gdrf_factorize": (_int, [_vp, _vp, _vp, _dbl, _vp]),
     "gdrf_step_local": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gdrf_step_local2": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -1246,6 +1246,21 @@ int gdrf_probe(gdrf_ctx* c, const void* Z, const void* params, const double* jit
   return 0;
 }
 
+// the two halves of gdrf_probe: the launch alone (asynchronous), and the read of its flags (waits for the stream)
+int gdrf_probe_launch(gdrf_ctx* c, const void* Z, const void* params, const double* jitters, int nlev, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (nlev < 1 || nlev > 8) return fail(-1, "gdrf_probe_launch", "nlev must be in [1, 8]");
+  return probe_dispatch(c, Z, params, jitters, nlev, (hipStream_t)stream);
+}
+int gdrf_probe_read(gdrf_ctx* c, int nlev, int* failed_host, void* stream) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (nlev < 1 || nlev > 8) return fail(-1, "gdrf_probe_read", "nlev must be in [1, 8]");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(failed_host, c->flag + 8, sizeof(int) * nlev, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
 int gdrf_factorize(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;

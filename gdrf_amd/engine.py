@@ -314,13 +314,20 @@ class Engine:
             # same parameters, so every rank takes the same branch.
             main = torch.cuda.current_stream(self.device)
             self._probe_stream.wait_stream(main)
+            ps = self._probe_stream.cuda_stream
+            # the probe of the first levels goes out FIRST, without waiting: it runs while the host enqueues the step
+            nlev0 = min(4, self.maxjitter)
+            jit0 = (C.c_double * nlev0)(*[self.jitter_total(l) for l in range(nlev0)])
+            _lib.check(self.lib.gdrf_probe_launch(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jit0, nlev0, ps), "gdrf_probe_launch")
             _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(guess), s),
                        "gdrf_factorize")
             fact_done = torch.cuda.Event()
             fact_done.record(main)
             self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
-            ps = self._probe_stream.cuda_stream
-            level = self._probe_level(ps)
+            flags0 = (C.c_int * nlev0)()
+            _lib.check(self.lib.gdrf_probe_read(self.ctx, nlev0, flags0, ps), "gdrf_probe_read")
+            ok0 = [l for l in range(nlev0) if not flags0[l]]
+            level = ok0[0] if ok0 else self._probe_level(ps, start=nlev0)
             failed = C.c_int()
             self._probe_stream.wait_event(fact_done)
             _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), ps), "gdrf_chol_failed")
@@ -346,9 +353,9 @@ class Engine:
         setattr(self, "_mean_g" if guide else "_mean", mean)    # keeps the storage alive while the context borrows it
         _lib.check(fn(self.ctx, mean.data_ptr(), mean.stride(0), mean.stride(1)), "gdrf_set_mean")
 
-    def _probe_level(self, stream_ptr: int) -> int:
-        """First cumulative-jitter level whose array-precision Cholesky succeeds (probe only; raises past maxjitter)."""
-        level = 0
+    def _probe_level(self, stream_ptr: int, start: int = 0) -> int:
+        """First cumulative-jitter level >= start whose array-precision Cholesky succeeds (probe only; raises past maxjitter)."""
+        level = start
         while level < self.maxjitter:
             nlev = min(4 if level == 0 else 8, self.maxjitter - level)
             jit = (C.c_double * nlev)(*[self.jitter_total(level + l) for l in range(nlev)])

@@ -125,6 +125,10 @@ int gdrf_ll_const_dev(gdrf_ctx* ctx, const int32_t* ws_dev, int64_t n, double* o
  * gdrf_factorize()/gdrf_step_local() of the same parameters (gdrf_amd.Engine overlaps it that way). */
 int gdrf_probe(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const double* jitters_host, int nlev,
                int* failed_host, void* stream);
+/* The same in two calls: the launch alone (asynchronous, so that the caller can enqueue the step it speculates on beside it) and
+ * the read of the flags of the last launch (waits for `stream`). */
+int gdrf_probe_launch(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, const double* jitters_host, int nlev, void* stream);
+int gdrf_probe_read(gdrf_ctx* ctx, int nlev, int* failed_host, void* stream);
 
 /* K_uu + jitter_total*I, its Cholesky factor L and L^{-1} in the solve precision, kept in the context for
  * the calls below. */

@@ -27,3 +27,18 @@ R = 50
 for _ in range(R): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / R
 print("n=%d: %.3f ms per step (host reads the loss each step)" % (n, dt * 1e3))
+# host enqueue time alone (no read of the loss inside the loop): what a captured graph would remove
+torch.cuda.synchronize(); h = 0.0
+for _ in range(R):
+    t1 = time.perf_counter()
+    eng.loss_and_grads(xs, ws, eps, n_global=1e6)
+    eng.adam("adam", 1e-5)
+    h += time.perf_counter() - t1
+    torch.cuda.synchronize()
+print("host enqueue per step: %.3f ms" % (h / R * 1e3))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(R):
+    eng.loss_and_grads(xs, ws, eps, n_global=1e6)
+    eng.adam("adam", 1e-5)
+torch.cuda.synchronize()
+print("back-to-back without reading the loss: %.3f ms per step" % ((time.perf_counter() - t0) / R * 1e3))
