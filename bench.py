@@ -256,7 +256,10 @@ def main():
         else:
             pipe, peak, nprod = ("f32" if dtype == torch.float32 else "f64"), (PEAK_F32_MFMA_TFLOPS if dtype == torch.float32 else PEAK_F64_MFMA_TFLOPS), 1
         issued = tile_factor.get(dom, 1.0) * nprod * f32_equiv        # MFMA flops actually issued per second, in TFLOP/s
-        kname = {"fwd_t": "fwd_t_split_2g_kernel", "bwd_wbar": "bwd_wbar_split_kernel", "tn_sym": "gemm_tn_split_kernel<A_k>",
+        f16 = eng.mfma_mode == "f16x3"
+        kname = {"fwd_t": "fwd_t_split_q4_kernel" if f16 else "fwd_t_split_cc_kernel",
+                 "bwd_wbar": "bwd_wbar_f16_k64_kernel" if f16 else "bwd_wbar_split_kernel",
+                 "tn_sym": "tn_topics_f16_kernel" if f16 else "gemm_tn_split_kernel<A_k>",
                  "tn_gt": "gemm_tn_split_kernel<GT>"}[dom] if split else (
             f"gemm_nt<{dom}>" if not dom.startswith("tn") else f"gemm_tn<{dom}>")
         # HBM bytes per launch of the dominant kernel from the PMC passes of this command (tools/profile_round.sh -> pmc_hbm.json)
@@ -298,9 +301,10 @@ def main():
                                  "products per multiply-add x whole-tile factor); f32_equivalent_tflops = algorithmic f32 flops / time"},
             "roofline_knm": {"bound": "hbm", "kernel": "knm_kernel<f32> (standalone, the metric's K_nm kernel)", "achieved": knm_gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": knm_gbs / PEAK_HBM_GBS, "traffic": knm_bytes,
-                             "traffic_note": "WRITE_SIZE of this kernel equals its algorithmic bytes (profiles/r01/bench_pmc_hbm.csv)",
+                             "traffic_note": "WRITE_SIZE of this kernel equals its algorithmic bytes (profiles/%s/pmc_hbm.json, k_nm_f32)" % PROFILE_ROUND,
                              "bytes_per_launch": knm_bytes, "avg_ms": knm_t * 1e3,
-                             "in_step": {"kernel": f"knm_kernel<f{8 * ssz}> (the launch inside the step: solve precision, feeds W = K_nm L^-T)",
+                             "in_step": {"kernel": ("knm_rbf_f64_kernel" if (ssz == 8 and args.kernel == "rbf") else f"knm_kernel<f{8 * ssz}>")
+                                                   + " (the launch inside the step: solve precision, feeds W = K_nm L^-T)",
                                          "achieved": knm_step_gbs, "peak": PEAK_HBM_GBS, "frac": knm_step_gbs / PEAK_HBM_GBS,
                                          "bytes_per_launch": knm_step_bytes, "avg_ms": ms["k_nm"]}},
             "step_f32_equivalent_tflops": survey_flops / world / (dt / args.steps) / 1e12,

@@ -7,8 +7,10 @@ reports half of a wide coalesced read stream on gfx950 (doubled here), WRITE_SIZ
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-SLOT = {"bwd_wbar": "bwd_wbar_split_kernel", "fwd_t": "fwd_t_split", "tn_sym": "tn_topics_f16_kernel", "tn_gt": "gemm_tn_split_kernel",
-        "fwd_w": "FwdWProb", "bwd_knm": "BwdKnmProb", "k_nm": "knm_kernel<double", "k_nm_f32": "knm_kernel<float"}
+# timing slot -> substrings of the kernel names that can fill it (the first kernel found wins; one of them runs per configuration)
+SLOT = {"bwd_wbar": ("bwd_wbar_f16_k64_kernel", "bwd_wbar_split"), "fwd_t": ("fwd_t_split",), "tn_sym": ("tn_topics_f16_kernel",),
+        "tn_gt": ("gemm_tn_split_kernel",), "fwd_w": ("FwdWProb",), "bwd_knm": ("BwdKnmProb",),
+        "k_nm": ("knm_rbf_f64_kernel", "knm_kernel<double"), "k_nm_f32": ("knm_kernel<float",)}
 
 
 def means(root, counter):
@@ -27,12 +29,14 @@ def main():
     out = {"N": d["config"]["N"], "mfma_mode": d["config"]["mfma_mode"], "kernels": {},
            "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE in separate passes of `bench.py --steps 1`, mean per dispatch; "
                    "traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE counts half of a wide read stream on gfx950)"}
-    for slot, pat in SLOT.items():
-        kw = [v for k, v in w.items() if pat in k]
-        kf = [v for k, v in f.items() if pat in k]
-        if kw and kf:
-            out["kernels"][slot] = {"write_bytes": kw[0] * 1024, "fetch_bytes_corrected": 2 * kf[0] * 1024,
-                                    "traffic_bytes": (2 * kf[0] + kw[0]) * 1024}
+    for slot, pats in SLOT.items():
+        for pat in pats:
+            kw = [(k, v) for k, v in w.items() if pat in k]
+            kf = [v for k, v in f.items() if pat in k]
+            if kw and kf:
+                out["kernels"][slot] = {"kernel": kw[0][0].split("(")[0][:96], "write_bytes": kw[0][1] * 1024, "fetch_bytes_corrected": 2 * kf[0] * 1024,
+                                        "traffic_bytes": (2 * kf[0] + kw[0][1]) * 1024}
+                break
     json.dump(out, sys.stdout, indent=1)
 
 

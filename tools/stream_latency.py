@@ -42,3 +42,8 @@ for _ in range(R):
     eng.adam("adam", 1e-5)
 torch.cuda.synchronize()
 print("back-to-back without reading the loss: %.3f ms per step" % ((time.perf_counter() - t0) / R * 1e3))
+eng.set_timing(True)
+for _ in range(20): step()
+torch.cuda.synchronize()
+tm = eng.get_timing()
+print("in-library timers (ms per step): " + " ".join("%s %.3f" % (k, v["ms"] / max(v["count"], 1)) for k, v in tm.items() if v["count"]))
