@@ -996,9 +996,11 @@ template <typename T, typename TS> struct Impl {
             const int ntl = tnt_ntiles(Mp), kgroups = (K + TNT_KT - 1) / TNT_KT;
             TNTopicsArgs ta{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbar, ldk, n, rpst, Mp,
                             (float*)c->slab, K, nst, ntl, (const float*)c->ssc, SL.w(), SL.v(0)};
-            constexpr int lds = 2 * 2 * 2 * 32 * 128 * 2 + 2 * TNT_KT * 32 * 4;
-            HIPCHK(hipFuncSetAttribute((const void*)tn_topics_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL(tn_topics_f16_kernel, dim3((unsigned)(ntl * kgroups * nst)), dim3(512), lds, s, ta);
+            static const int pph = getenv("GDRF_TNT_PPH") ? atoi(getenv("GDRF_TNT_PPH")) : 3;     // topic pairs per phase (A/B knob)
+#define GDRF_TNT(X) { HIPCHK(hipFuncSetAttribute((const void*)tn_topics_f16_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, tnt_lds_bytes(X))); \
+                      hipLaunchKernelGGL(tn_topics_f16_kernel<X>, dim3((unsigned)(ntl * kgroups * nst)), dim3(512), tnt_lds_bytes(X), s, ta); }
+            if (pph == 1) GDRF_TNT(1) else if (pph == 2) GDRF_TNT(2) else GDRF_TNT(3)
+#undef GDRF_TNT
             LAUNCHCHK("tn_topics");
             red_ns = nst; red_qd = 32;
           }

@@ -41,17 +41,21 @@ __host__ __device__ inline int tnt_ntiles(int ncols) {
   return t;
 }
 
+// PPH = topic pairs per phase (one barrier per phase).  With one pair a wave issues 24 MFMAs between barriers (384 pipe cycles against
+// ~300 of barrier and ramp); with three the ten topics of a chunk are two phases (3 + 2 pairs) instead of five, at 2 x PPH B images.
+constexpr int tnt_lds_bytes(int pph) { return 2 * 2 * 32 * 128 * 2 + 2 * pph * 2 * 32 * 128 * 2 + 2 * TNT_KT * 32 * 4; }
+template <int PPH>
 __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
   using SP = SplitF16;
   using E = _Float16;
   using V8 = f16x8;
   using V4 = f16x4;
-  constexpr int NP = 2, KT = TNT_KT, NPAIR = KT / 2;
+  constexpr int NP = 2, KT = TNT_KT, NPAIR = KT / 2, NPH = (NPAIR + PPH - 1) / PPH;
   constexpr int PIECE = 32 * 128;                       // halfwords per piece image (8 KB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   E* As = reinterpret_cast<E*>(smem);                   // [2 buffers][NP][32][128]
-  E* Bs = As + 2 * NP * PIECE;                          // [2 buffers][NP][32][128]: a topic pair's 64 + 64 columns
-  float* vtab = reinterpret_cast<float*>(Bs + 2 * NP * PIECE);     // [2 buffers][KT][32]: vbar_kn x block scale (0 for rows past the end)
+  E* Bs = As + 2 * NP * PIECE;                          // [2 buffers][PPH pairs][NP][32][128]: a topic pair's 64 + 64 columns
+  float* vtab = reinterpret_cast<float*>(Bs + 2 * PPH * NP * PIECE);   // [2 buffers][KT][32]: vbar_kn x block scale (0 for rows past the end)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave_u >> 1, wj = wave_u & 1, lr = lane & 15, lg = lane >> 4;
@@ -111,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
       vtab[((c & 1) * KT + kk) * 32 + row] = v;
     }
   };
-  // split x (4 columns of this lane's row) for the topic pair pr of chunk c into B image buffer q
-  auto split_pair = [&](const f32x4& x, int c, int pr, int q) {
+  // split x (4 columns of this lane's row) for the topic pair pr of chunk c into B image (buffer q, slot sl)
+  auto split_pair = [&](const f32x4& x, int c, int pr, int q, int sl) {
     const float* vt = vtab + ((c & 1) * KT + 2 * pr) * 32 + brow;
     const float okf = b_ok ? 1.0f : 0.0f;
     const float v0 = vt[0] * okf, v1 = vt[32] * okf;                      // 2 pr + 1 < KT always (KT even); unconditional LDS reads
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
     for (int t = 0; t < 2; ++t) {
       const int so = tnb_seg(brow, bc4 + 16 * t) * 4;
 #pragma unroll
-      for (int s = 0; s < NP; ++s) *reinterpret_cast<V4*>(Bs + (q * NP + s) * PIECE + so) = pv[t][s];
+      for (int s = 0; s < NP; ++s) *reinterpret_cast<V4*>(Bs + ((q * PPH + sl) * NP + s) * PIECE + so) = pv[t][s];
     }
   };
   // fragments (geometry of gemm_tn_split_kernel): two transposing reads of 4 rows x 16 columns each
@@ -147,13 +151,15 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
   };
 
   if (nch > 0) {
-    // ---- prologue: chunk 0's A image, row factors and first B pair
+    const int nph = (npair + PPH - 1) / PPH;
+    // ---- prologue: chunk 0's A image, row factors and the B images of its first phase
     dma_a(0);
     f32x4 rb = load_b(0);
     stage_v(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase_barrier();
-    split_pair(rb, 0, 0, 0);
+#pragma unroll
+    for (int sl = 0; sl < PPH; ++sl) if (sl < npair) split_pair(rb, 0, sl, 0, sl);
     phase_barrier();
     int q = 0;
     V8 fa[2][NP];
@@ -161,9 +167,11 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
       f32x4 rbn = rb;
       const bool more = c + 1 < nch;
 #pragma unroll
-      for (int pr = 0; pr < NPAIR; ++pr) {
-        if (pr < npair) {
-          if (pr == 0) {
+      for (int ph = 0; ph < NPH; ++ph) {
+        if (ph < nph) {
+          constexpr int dummy = 0; (void)dummy;
+          const int first = PPH * ph;
+          if (ph == 0) {
             if (active) {
 #pragma unroll
               for (int a = 0; a < 2; ++a)
@@ -174,31 +182,38 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
               dma_a(c + 1);
               rbn = load_b(c + 1);
               stage_v(c + 1);
-              if (npair == 1) phase_barrier(); // the factors are used by the split below in this same phase when there is only one pair
+              if (nph == 1) phase_barrier();   // the factors are used by the splits below in this same phase when a chunk is one phase
             }
           }
-          // produce the next B image while this one is multiplied (all four fragments of the pair up front cost 16 registers more
-          // than the 256 a two-waves-per-SIMD kernel has: spills, 10.1 -> 11.0 ms)
-          if (pr + 1 < npair) split_pair(rb, c, pr + 1, q ^ 1);
-          else if (more) split_pair(rbn, c + 1, 0, q ^ 1);
-          if (active) {
+          const bool same = ph + 1 < nph;      // the next phase belongs to this chunk
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              V8 fb[2][NP];
+          for (int sl = 0; sl < PPH; ++sl) {
+            // produce slot sl of the next phase's B images while this phase's are multiplied (all fragments of a pair up front cost 16
+            // registers more than the 256 a two-waves-per-SIMD kernel has: spills, 10.1 -> 11.0 ms)
+            if (same) { if (first + PPH + sl < npair) split_pair(rb, c, first + PPH + sl, q ^ 1, sl); }
+            else if (more) { if (sl < npair) split_pair(rbn, c + 1, sl, q ^ 1, sl); }
+            if (first + sl < NPAIR) {
+              if (active && first + sl < npair) {
 #pragma unroll
-              for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int s = 0; s < NP; ++s) fb[b][s] = frag(Bs + (q * NP + s) * PIECE, 4 * t + 2 * wj + b);
-#pragma unroll
-              for (int x = 0; x < SP::NPROD; ++x)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int t = 0; t < 2; ++t) {
+                  V8 fb[2][NP];
 #pragma unroll
                   for (int b = 0; b < 2; ++b)
-                    acc[2 * pr + t][a][b] = SP::mma(fa[a][SP::pa(x)], fb[b][SP::pb(x)], acc[2 * pr + t][a][b]);
+#pragma unroll
+                    for (int s = 0; s < NP; ++s) fb[b][s] = frag(Bs + ((q * PPH + sl) * NP + s) * PIECE, 4 * t + 2 * wj + b);
+#pragma unroll
+                  for (int x = 0; x < SP::NPROD; ++x)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                      for (int b = 0; b < 2; ++b)
+                        acc[(2 * (first + sl) + t) < KT ? 2 * (first + sl) + t : 0][a][b] =
+                            SP::mma(fa[a][SP::pa(x)], fb[b][SP::pb(x)], acc[(2 * (first + sl) + t) < KT ? 2 * (first + sl) + t : 0][a][b]);
+                }
+              }
             }
           }
-          if (pr + 1 == npair && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of A(c + 1) has landed
+          if (ph + 1 == nph && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of A(c + 1) has landed
           phase_barrier();
           q ^= 1;
         }
