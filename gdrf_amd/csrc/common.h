@@ -6,6 +6,9 @@
 #define GDRF_WAVE 64
 #define GDRF_TILE 128          // output tile edge of both GEMM cores
 #define GDRF_KBYTES 128        // bytes of reduction index staged per row per chunk (NT core)
+#ifndef GDRF_FWDW_WGS
+#define GDRF_FWDW_WGS 2         // workgroups per CU the f64 W = K_nm L^-T kernel's register allocation leaves room for (2: 144 registers, 3 resident)
+#endif
 #ifndef GDRF_KBYTES_F64
 #define GDRF_KBYTES_F64 0      // the same for f64 operands (0: GDRF_KBYTES).  256 (32 doubles per chunk, half the barriers per MFMA) was
                                // measured SLOWER: 180 registers -> 2 workgroups per CU, fwd_w 6.55 -> 7.03 ms

@@ -240,6 +240,7 @@ template <typename T, typename TN, bool DERIV = false, int DD = 2> struct FwdWPr
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
   static constexpr int DEPTH = 1;
+  static constexpr int MIN_WGS = (sizeof(T) == 8 && !DERIV) ? GDRF_FWDW_WGS : 2;
   const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
   const TN* X = nullptr; const T* Z = nullptr; const Hyper* h = nullptr; int M = 0, D = 0, kind = 0;   // DERIV only
