@@ -607,6 +607,29 @@ template <typename T, typename TS> struct Impl {
         }
         return 0;
       }
+      if constexpr (SP::NP == 2) {
+        if (const char* sw = getenv("GDRF_STAMP_Q4")) {      // diagnostic: s_memtime stamps of wave <value> of one workgroup of the 256 x 256 form
+          unsigned long long* d = nullptr;
+          HIPCHK(hipMalloc((void**)&d, 64 * 5 * 8)); HIPCHK(hipMemset(d, 0, 64 * 5 * 8));
+          FwdTSplitArgs<SP> as = a; as.stamps = d; as.KG = KG | (atoi(sw) << 16);
+          constexpr int lds4 = 8 * SplitCfg<SP>::IMG * 2 + 8 * GDRF_TILE * 4 + 64 * 5 * 8;
+          HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_q4_kernel<SP, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+          hipLaunchKernelGGL((fwd_t_split_q4_kernel<SP, 17>), dim3((unsigned)(8 * K * rt8)), dim3(1024), lds4, s, as);
+          std::vector<unsigned long long> h(64 * 5);
+          HIPCHK(hipStreamSynchronize(s));
+          HIPCHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost)); (void)hipFree(d);
+          double m[5] = {0, 0, 0, 0, 0}; int cnt = 0; std::string line;
+          for (int t = 1; t < 24; ++t) {
+            const unsigned long long* q = &h[t * 5];
+            if (!q[4]) break;
+            m[0] += q[1] - q[0]; m[1] += q[2] - q[1]; m[2] += q[3] - q[2]; m[3] += q[4] - q[3]; m[4] += q[0] - h[(t - 1) * 5 + 4]; ++cnt;
+            line += " " + std::to_string(q[4] - h[(t - 1) * 5 + 4]);
+          }
+          if (cnt) fprintf(stderr, "fwd_t q4 stamps wave %d (%d phases): dma+frag issue %.0f  mfma loop %.0f  vmcnt+lgkm %.0f  barrier %.0f  between %.0f | phase lengths:%s\n",
+                           atoi(sw), cnt, m[0] / cnt, m[1] / cnt, m[2] / cnt, m[3] / cnt, m[4] / cnt, line.c_str());
+          return 0;
+        }
+      }
       const char* alt = getenv("GDRF_FWDT_ALTERNATING");          // A/B knob: the phase-alternating form
       if (alt && alt[0] == '1') {
         HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));

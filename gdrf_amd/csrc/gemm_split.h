@@ -1286,12 +1286,13 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
   const int Mp = g.Mp;
   const int nct = (Mp + GDRF_TILE - 1) / GDRF_TILE, ncp = (nct + 1) / 2;
   const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-  const unsigned per_group = (unsigned)g.KG * (unsigned)g.rt8;
+  const int KGv = (VAR & 16) ? (g.KG & 0xffff) : g.KG;     // (the stamped build carries the wave to stamp in the high half)
+  const unsigned per_group = (unsigned)KGv * (unsigned)g.rt8;
   const int grp = (int)(idx / per_group);
   const unsigned rem = idx - (unsigned)grp * per_group;
-  const int kg = min(g.KG, g.K - grp * g.KG);
+  const int kg = min(KGv, g.K - grp * KGv);
   const int64_t rt0 = 2 * ((int64_t)(rem / (unsigned)kg) * 8 + xcd);   // the pair's first row tile
-  const int bz = grp * g.KG + (int)(rem % (unsigned)kg);
+  const int bz = grp * KGv + (int)(rem % (unsigned)kg);
   const int64_t m0 = (rt0 + gr) * GDRF_TILE;                   // a tile past the end runs on clamped rows; its tt is never stored
 
   const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
@@ -1328,6 +1329,13 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
   // is folded into it by its own wave (no other writer), so the order of the additions is fixed
   float* rsum = reinterpret_cast<float*>(smem + (size_t)8 * IMG * 2) + (gp * 2 + wc) * GDRF_TILE;
   rsum[wr * 64 + lane] = 0.0f;                            // this wave's 64 rows (ordered before its own later updates: same wave, LDS in order)
+  // diagnostic builds (VAR & 16): s_memtime at five points of every multiply phase of one wave of one workgroup, kept in LDS
+  unsigned long long* lstamp = reinterpret_cast<unsigned long long*>(smem + (size_t)8 * IMG * 2 + 8 * GDRF_TILE * 4);   // [64][5]
+  const bool stamping = (VAR & 16) && blockIdx.x == 20000 && w16 == (int)(g.KG >> 16) && lane == 0;
+  int sphase = 0;
+  auto stamp = [&](int i) {
+    if (VAR & 16) { __builtin_amdgcn_sched_barrier(0); if (stamping && sphase < 64) lstamp[sphase * 5 + i] = split_stamp(); __builtin_amdgcn_sched_barrier(0); }
+  };
   f32x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -1372,6 +1380,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
       next_chunk(cp, kA, cp1, kA1);
       const E* Ab = Asm + (gr * 2 + buf) * IMG;
       const E* Bb = Bsm + (gc * 2 + buf) * IMG;
+      stamp(0);
       if (VAR & 1) {
 #pragma unroll
         for (int sl = 0; sl < 2 * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
@@ -1381,6 +1390,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
       for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+      stamp(1);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (!(VAR & 2)) __builtin_amdgcn_sched_barrier(0);       // keeps hipcc from hoisting the later row blocks' reads
@@ -1396,9 +1406,13 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
           for (int sl = a * NP; sl < (a + 1) * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
         }
       }
+      stamp(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of the next chunk have landed (they had the whole phase)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(3);
       __builtin_amdgcn_s_barrier();
+      stamp(4);
+      if (VAR & 16) ++sphase;
       buf ^= 1;
     }
     if (ct < nct) {                                             // fold the finished column tile into the row sums, restart the accumulators
@@ -1425,6 +1439,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
   }
   // the four partial sums of a row (2 column groups x 2 wave columns), added in a fixed order
   __syncthreads();
+  if (VAR & 16) { if (stamping) for (int i = 0; i < 64 * 5; ++i) g.stamps[i] = lstamp[i]; }
   if (gc == 0 && tid < GDRF_TILE) {
     const float* q = reinterpret_cast<const float*>(smem + (size_t)8 * IMG * 2) + (gr * 2) * 2 * GDRF_TILE + tid;
     const float v = (q[0] + q[GDRF_TILE]) + (q[2 * GDRF_TILE] + q[3 * GDRF_TILE]);
