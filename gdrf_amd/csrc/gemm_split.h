@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
       const E* Ab = Asm + (gr * 2 + buf) * IMG;
       const E* Bb = Bsm + (gc * 2 + buf) * IMG;
       stamp(0);
-      if (VAR & 1) {
+      if ((VAR & 1) && !(VAR & 4)) {
 #pragma unroll
         for (int sl = 0; sl < 2 * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
       }
@@ -1390,13 +1390,24 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
       for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const V8*>(Bb + p * CF::PIECE + (wc * 64 + b * 16) * 32 + frag);
+      V8 fa0[NP];
+      if (VAR & 4) {                                             // the first fragments are requested BEFORE the DMAs: their latency runs under the request stalls
+#pragma unroll
+        for (int p = 0; p < NP; ++p) fa0[p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64) * 32 + frag);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 0; sl < 2 * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
+      }
       stamp(1);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (!(VAR & 2)) __builtin_amdgcn_sched_barrier(0);       // keeps hipcc from hoisting the later row blocks' reads
         V8 fa[NP];                                               // one row block at a time: the SIMD's other three waves cover the read
 #pragma unroll
-        for (int p = 0; p < NP; ++p) fa[p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
+        for (int p = 0; p < NP; ++p) {
+          if ((VAR & 4) && a == 0) fa[p] = fa0[p];
+          else fa[p] = *reinterpret_cast<const V8*>(Ab + p * CF::PIECE + (wr * 64 + a * 16) * 32 + frag);
+        }
 #pragma unroll
         for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
