@@ -640,7 +640,7 @@ template <typename T, typename TS> struct Impl {
           static const int var = getenv("GDRF_Q4_VAR") ? atoi(getenv("GDRF_Q4_VAR")) : 1;      // A/B knob; 1 (requests first) measured best
 #define GDRF_Q4(X) { HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_q4_kernel<SP, X>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4)); \
                      hipLaunchKernelGGL((fwd_t_split_q4_kernel<SP, X>), dim3((unsigned)(8 * K * rt8)), dim3(1024), lds4, s, a); }
-          if (var == 1) GDRF_Q4(1) else if (var == 2) GDRF_Q4(2) else if (var == 3) GDRF_Q4(3) else if (var == 5) GDRF_Q4(5) else GDRF_Q4(0)
+          if (var == 1) GDRF_Q4(1) else if (var == 2) GDRF_Q4(2) else if (var == 3) GDRF_Q4(3) else if (var == 5) GDRF_Q4(5) else if (var == 33) GDRF_Q4(33) else GDRF_Q4(0)
 #undef GDRF_Q4
         }
       } else {

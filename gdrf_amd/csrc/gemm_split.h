@@ -1309,6 +1309,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
     b_off[sl] = (unsigned)(r * 32 + dq) * 2u;
   }
   auto dma1 = [&](int cp, int kA, int buf, int slot) {
+    if ((VAR & 32) && (cp > 0 || kA > 0)) return;            // timing-only ablation (results wrong): no requests after the prologue
     const int sl = slot < NP ? slot : slot - NP;
     const int rq = w16 * NP + sl, gi = rq / (8 * NP), rm = rq - gi * 8 * NP, p = rm >> 3, rbk = rm & 7;
     if (slot < NP) {
@@ -1457,7 +1458,9 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
     const int64_t m = m0 + tid;
     const SplitLay SL{g.K};
     const float un = g.sc[SL.w() + 1] * g.sc[SL.st(bz) + 1];
-    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = v * (un * un);
+    float o = v * (un * un);
+    if (VAR & 32) o = 1.0f + ((o == o && fabsf(o) < 1e30f) ? o * 1e-30f : 0.0f);       // ablated builds compute garbage: keep it finite and positive
+    if (m < g.nrows) g.tt[(int64_t)bz * g.ldt + m] = o;
   }
 }
 
