@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000, help="global number of observations (lattice side^2)")
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=1_000_000,
+                    help="global number of observations (lattice side^2); --rows is the spelling to use under torch.distributed.run, whose own parser claims --n")
     ap.add_argument("--n-points", type=int, nargs="+", default=[32, 16])
     ap.add_argument("--topics", type=int, default=10)
     ap.add_argument("--vocab", type=int, default=50)
@@ -151,11 +152,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
+    # rehearsal knobs (never set by the driver): GDRF_BENCH_ONE_GPU=1 puts every rank on cuda:0 and GDRF_BENCH_BACKEND=gloo replaces RCCL, so that
+    # the N > 1 code path of this file can be run on a one-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("GDRF_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("GDRF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from gdrf_amd.data import synth_circles
     from gdrf_amd.infer import SVI, Trace_ELBO
