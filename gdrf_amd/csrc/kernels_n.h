@@ -1449,6 +1449,27 @@ __global__ __launch_bounds__(128) void predict_rows_kernel(const TN* __restrict_
     T lc[GDRF_KMAX];
 #pragma unroll
     for (int k = 0; k < GDRF_KMAX; ++k) lc[k] = 0;
+    bool done = false;
+    if constexpr (sizeof(T) == 8) {
+      if (kind == 0) {
+        // RBF in double: k = 2^(log2 var - sum_d (a x_d - a z_d)^2) through the straight-line polynomial of knm_rbf_f64_kernel instead of
+        // the library exp() per (row, inducing point) - this loop is N x M of them
+        const double a = sqrt(0.5 * 1.4426950408889634074 * (double)ils2), lv = log2((double)var);
+        double xa[GDRF_DMAX];
+#pragma unroll
+        for (int d = 0; d < GDRF_DMAX; ++d) xa[d] = a * (double)x[d];
+        for (int i = 0; i < M; ++i) {
+          double t = lv;
+#pragma unroll
+          for (int d = 0; d < GDRF_DMAX; ++d) if (d < D) { const double dd = xa[d] - a * (double)Zs[i * D + d]; t = fma(-dd, dd, t); }
+          const double kv = exp2_poly(t);
+#pragma unroll
+          for (int k = 0; k < GDRF_KMAX; ++k) if (k < K) lc[k] += kv * Cs[k * M + i];
+        }
+        done = true;
+      }
+    }
+    if (!done)
     for (int i = 0; i < M; ++i) {
       T r2 = 0;
 #pragma unroll

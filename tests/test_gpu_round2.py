@@ -306,3 +306,78 @@ def test_panelwise_cholesky_backward_error_and_block_inverse(npts):
     assert res < 4e-15 and res < 8 * res_ref + 1e-16
     assert np.abs(Li @ L - np.eye(m.M)).max() < 1e-7                    # forward error of the inverse: condition-number bound, not round-off
     assert relerr(L, ref) < 1e-8
+
+
+def _oracle_3d(dtype, kind="rbf", learn_inducing=False, seed=3, n=420, V=11, K=3, n_points=(4, 3, 3)):
+    """Spatiotemporal inputs (x, y, t) in the unit cube: the D = 3 shape of the reference's data (index columns of the CSV)."""
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.rand(n, 3, generator=g, dtype=torch.float64)
+    ws = torch.randint(0, 9, (n, V), generator=g, dtype=torch.int32)
+    Z = None
+    if learn_inducing:
+        M = int(np.prod(n_points))
+        Z = 0.05 + 0.9 * torch.rand(M, 3, generator=g, dtype=torch.float64)
+    m = RefShapedGDRF3(xs, ws, kind=kind, K=K, n_points=n_points, dtype=dtype, jitter=1e-6 if dtype == torch.float64 else 1e-4, lengthscale=0.3,
+                       Z=Z, learn_inducing=learn_inducing, optimizer="adam", lr=1e-2)
+    with torch.no_grad():
+        m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64).to(dtype))
+        m.params["u_scale_tril_unc"].add_(0.1 * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril().to(dtype))
+        m.params["phi_unc"].add_(0.5 * torch.randn(m.params["phi_unc"].shape, generator=g, dtype=torch.float64).to(dtype))
+    eps = torch.randn(K, n, generator=g, dtype=torch.float64).to(dtype)
+    return m, eps
+
+
+from oracle.gdrf_oracle import RefShapedGDRF as RefShapedGDRF3  # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("learn_inducing", [False, True])
+def test_three_dimensional_inputs_fp64(kind, learn_inducing):
+    """D = 3 (x, y, t): the K_nm kernels' generic-dimension instantiations, the backward epilogue's general form (the LDS-transposed
+    one is for D <= 2) and the inducing-input gradient in three dimensions: loss and every gradient against autograd, then five Adam
+    steps."""
+    m, eps = _oracle_3d(torch.float64, kind=kind, learn_inducing=learn_inducing)
+    eng = engine_from_oracle(m)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    eng.loss_and_grads(xs, ws, dev(eps, eng))
+    out = eng.read_out()
+    assert out["chol_failed"] == 0
+    m.force_jitter_level = eng.last_jitter_level
+    loss_ref, grads_ref = m.loss_and_grads(eps)
+    assert abs(out["loss"] - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref)
+    gv = eng.named_views(eng.grads)
+    names = list(eng.PARAM_NAMES) + (["inducing_unc"] if learn_inducing else [])
+    for name in names:
+        assert relerr(gv[name].cpu().double().numpy(), grads_ref[name].double().numpy()) < 1e-7, name
+    g = torch.Generator().manual_seed(9)
+    for step in range(5):
+        e = torch.randn(m.K, m.N, generator=g, dtype=torch.float64)
+        loss_ref = m.step(e)
+        eng.loss_and_grads(xs, ws, dev(e, eng))
+        eng.adam("adam", 1e-2)
+        assert abs(eng.read_out()["loss"] - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref), step
+    for name in names:
+        assert relerr(eng.view(name).cpu().numpy(), m.params[name].detach().numpy()) < 1e-7, name
+
+
+def test_three_dimensional_inputs_fp32_and_predictive():
+    """The same shape through the float32 arrays + float64 solve configuration (f16x3 contractions), and the predictive path."""
+    m, eps = _oracle_3d(torch.float32)
+    eng = engine_from_oracle(m)
+    xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    eng.loss_and_grads(xs, ws, dev(eps, eng))
+    out = eng.read_out()
+    m64, _ = _oracle_3d(torch.float64)
+    with torch.no_grad():
+        for name in m.params:
+            m64.params[name].copy_(m.params[name].double())
+    m64.jitter = m.jitter
+    m64.force_jitter_level = eng.last_jitter_level
+    loss_ref, grads_ref = m64.loss_and_grads(eps.double(), xs=m.xs.double())
+    assert abs(out["loss"] - loss_ref) <= 1e-4 * abs(loss_ref)
+    gv = eng.named_views(eng.grads)
+    for name in eng.PARAM_NAMES:
+        assert relerr(gv[name].cpu().double().numpy(), grads_ref[name].numpy()) < 2e-2, name
+    tp = eng.predict(xs, 1).cpu().double().numpy()                      # topic_probs (n, K)
+    with torch.no_grad():
+        assert np.abs(tp - m64.topic_probs(m.xs.double()).numpy()).max() < 1e-4
