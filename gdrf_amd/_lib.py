@@ -40,6 +40,7 @@ SIGNATURES = {
     "gdrf_probe_read": (_int, [_vp, _int, C.POINTER(_int), _vp]),
     "gdrf_factorize": (_int, [_vp, _vp, _vp, _dbl, _vp]),
     "gdrf_step_local": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gdrf_step_local_link": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64]),
     "gdrf_step_local2": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gdrf_set_mean_guide": (_int, [_vp, _vp, _i64, _i64]),
     "gdrf_step_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),

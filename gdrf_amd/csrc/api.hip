@@ -1106,6 +1106,34 @@ template <typename T, typename TS> struct Impl {
     return 0;
   }
 
+  // one svi.step around a caller-supplied link function, in three calls (kernels_n.h: elbo_rows_link_kernel):
+  //   phase 0: transforms + forward + mu -> workspace 14;  phase 1: ext = theta (K, ext_ld) -> thetabar in workspace 6 (locbar), Phi-bar,
+  //   the log-likelihood sum;  phase 2: ext = mubar (K, ext_ld) -> the Normal sites, the row-local backward and the rest of gdrf_step_local
+  static int step_local_link(gdrf_ctx* c, const T* X, const int32_t* ws, const T* eps, int64_t n, const T* Z, const T* params,
+                             T* redT, double* redd, hipStream_t s, int phase, const T* ext, int64_t ext_ld) {
+    const int K = c->K, V = c->V;
+    const int64_t ldk = c->ldk;
+    int rc;
+    if (phase == 0 && (rc = step_local(c, X, ws, eps, n, Z, params, redT, redd, s, SL_TRANSFORMS | SL_FORWARD))) return rc;
+    const int RB = 64;
+    const size_t lds = 128 + ((size_t)2 * K * V + (size_t)RB * (K + 1) + (size_t)RB * (V + 1)) * sizeof(T);
+    if (lds > 150 * 1024) return fail(-1, "gdrf_step_local_link", "num_topic_categories x num_observation_categories too large for the row kernel's LDS");
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)elbo_rows_link_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int egrid = (int)std::min<int64_t>((n + RB - 1) / RB, c->erows_grid_cap);
+    hipLaunchKernelGGL(elbo_rows_link_kernel<T>, dim3(egrid), dim3(RB), lds, s, phase, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt),
+                       eps, ldk, n, ws, P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, ext, ext_ld, P(c->q), P(c->vbar), P(c->locbar),
+                       P(c->asum), P(c->mu), c->dpart, P(c->phibar_part));
+    LAUNCHCHK("elbo_rows_link");
+    if (phase == 1)
+      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid, (int64_t)K * V,
+                         redT + roff(c, 1));
+    if (phase == 2) {
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+      return step_local(c, X, ws, eps, n, Z, params, redT, redd, s, SL_BACKWARD);
+    }
+    return 0;
+  }
+
   static int step_finish(gdrf_ctx* c, const T* Z, const T* params, const T* redT, const double* redd, double n_global,
                          double ll_const, T* grads, double* out_d, hipStream_t s) {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
@@ -1298,6 +1326,16 @@ int gdrf_step_local(gdrf_ctx* c, const void* X, const int32_t* ws, const void* e
   if (n < 1 || n > c->ncap) return fail(-1, "gdrf_step_local", "n_local outside [1, n_cap]");
   hipStream_t s = (hipStream_t)stream;
   TYPED3(c, step_local, c, (const T*)X, ws, (const T*)eps, n, (const T*)Z, (const T*)params, (T*)redT, redd, s);
+}
+
+int gdrf_step_local_link(gdrf_ctx* c, const void* X, const int32_t* ws, const void* eps, int64_t n, const void* Z, const void* params,
+                         void* redT, double* redd, void* stream, int phase, const void* ext, int64_t ext_ld) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (n < 1 || n > c->ncap) return fail(-1, "gdrf_step_local_link", "n_local outside [1, n_cap]");
+  if (phase < 0 || phase > 2) return fail(-1, "gdrf_step_local_link", "phase must be 0, 1 or 2");
+  if (phase > 0 && (!ext || ext_ld < n)) return fail(-1, "gdrf_step_local_link", "phases 1 and 2 take a (K, ext_ld >= n) array");
+  hipStream_t s = (hipStream_t)stream;
+  TYPED3(c, step_local_link, c, (const T*)X, ws, (const T*)eps, n, (const T*)Z, (const T*)params, (T*)redT, redd, s, phase, (const T*)ext, ext_ld);
 }
 
 int gdrf_step_local2(gdrf_ctx* c, const void* X_model, const void* X_guide, const int32_t* ws, const void* eps, int64_t n, const void* Z,

@@ -1082,6 +1082,135 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
   for (int e = threadIdx.x; e < K * V; e += RB) phibar_part[(int64_t)blockIdx.x * K * V + e] = accS[e];
 }
 
+// The per-row terms around a CALLER-SUPPLIED link function (the reference's `link_function` constructor argument,
+// gdrf/models/abstract_gdrf.py:34-50, applied as `self._link_function(mu).transpose(-2, -1)` in sparse_gdrf.py:361): the link and
+// its Jacobian are evaluated by the host between three launches of this kernel (one thread per row, any K; not a hot path).
+//   phase 0: q, v, mu = loc + v eps (+ mean)            -> mu_out (K, ldk)
+//   phase 1: theta = ext (K, ext_ld) as returned by the link: p = theta^T Phi, Multinomial log-likelihood of the normalised p,
+//            thetabar_k = sum_v Phi_kv w_v / p_v - sum_v w_v / sum_v p_v  (theta need not sum to one) -> locbar (K, ldk), Phi-bar partials
+//   phase 2: mubar = ext (K, ext_ld), the pull-back of thetabar through the link: both Normal sites and the row-local backward
+// dpart[block][4]: phase 1 writes slot 1 (sum w log p), phase 2 slots 0, 2, 3 (site, d/d noise, a sum vbar) - same grid in both.
+template <typename T>
+__global__ __launch_bounds__(64) void elbo_rows_link_kernel(
+    int phase, int64_t nrows, int K, int V, const Hyper* __restrict__ h,
+    const T* __restrict__ qpart, int nqpart, const T* __restrict__ loc, const T* __restrict__ tt, const T* __restrict__ eps,
+    int64_t ldk, int64_t lde, const int32_t* __restrict__ ws, const T* __restrict__ phi,
+    const T* __restrict__ mean /*may be null*/, int64_t mean_sk, int64_t mean_sn,
+    const T* __restrict__ ext, int64_t ext_ld,
+    T* __restrict__ qout, T* __restrict__ vbar, T* __restrict__ locbar, T* __restrict__ asum, T* __restrict__ mu_out,
+    double* __restrict__ dpart /*[grid][4]*/, T* __restrict__ phibar_part /*[grid][K*V]*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int RB = blockDim.x;
+  double* scratch = reinterpret_cast<double*>(smem);    // [16]
+  T* phiS = reinterpret_cast<T*>(smem + 128);           // [K*V]
+  T* accS = phiS + K * V;                               // [K*V]
+  T* thS = accS + K * V;                                // [RB][K+1]
+  T* pbS = thS + RB * (K + 1);                          // [RB][V+1]
+  if (phase == 1) {
+    for (int e = threadIdx.x; e < K * V; e += RB) { phiS[e] = phi[e]; accS[e] = 0; }
+    __syncthreads();
+  }
+  const T var = (T)h->var, eta = (T)h->noise;
+  const T feps = t_eps<T>();
+  double s_site = 0, s_llw = 0, s_noise = 0, s_vd = 0;
+  const int64_t nblk = (nrows + RB - 1) / RB;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t n = blk * RB + threadIdx.x;
+    const bool ok = n < nrows;
+    T* th = thS + threadIdx.x * (K + 1);
+    T* pb = pbS + threadIdx.x * (V + 1);
+    if (phase != 1) {
+      if (ok) {
+        T qn = 0;
+        for (int c = 0; c < nqpart; ++c) qn += qpart[(int64_t)c * ldk + n];
+        const T a = (var - qn > T(0)) ? T(1) : T(0);
+        const T v0 = a * (var - qn);
+        if (phase == 0) qout[n] = qn;
+        T site = 0, ng = 0, vsum = 0;
+        for (int k = 0; k < K; ++k) {
+          const T ek = eps[(int64_t)k * lde + n];
+          const T vk = v0 + tt[(int64_t)k * ldk + n];
+          if (phase == 0) {
+            T mk = loc[(int64_t)k * ldk + n] + vk * ek;
+            if (mean) mk += mean[(int64_t)k * mean_sk + n * mean_sn];
+            mu_out[(int64_t)k * ldk + n] = mk;
+          } else {
+            const T mub = ext[(int64_t)k * ext_ld + n];
+            const T sk = vk + eta, r = vk / sk, e2 = ek * ek;
+            site += -t_log<T>(sk) + t_log<T>(vk) - T(0.5) * e2 * r * r + T(0.5) * e2;
+            const T dcdv = -T(1) / sk + T(1) / vk - e2 * r * eta / (sk * sk);
+            ng += -T(1) / sk + e2 * r * r / sk;
+            const T vb = mub * ek + dcdv;
+            vbar[(int64_t)k * ldk + n] = vb;
+            locbar[(int64_t)k * ldk + n] = mub;
+            vsum += vb;
+          }
+        }
+        if (phase == 2) {
+          const T vd = a * vsum;
+          asum[n] = vd;
+          s_site += (double)site; s_noise += (double)ng; s_vd += (double)vd;
+        }
+      }
+      continue;
+    }
+    // ---- phase 1
+    if (ok) {
+      for (int k = 0; k < K; ++k) th[k] = ext[(int64_t)k * ext_ld + n];
+      T ps = 0;
+      for (int vv = 0; vv < V; ++vv) {
+        T p = 0;
+        for (int k = 0; k < K; ++k) p += th[k] * phiS[k * V + vv];
+        pb[vv] = p;
+        ps += p;
+      }
+      const T ips = T(1) / ps;
+      T llw = 0, wsum = 0;
+      for (int vv = 0; vv < V; ++vv) {
+        const T p = pb[vv];
+        const T ph = p * ips;
+        const T wv = (T)ws[n * V + vv];
+        const bool inr = (ph > feps) && (ph < T(1) - feps);
+        const T phc = fmin(fmax(ph, feps), T(1) - feps);
+        llw += wv * t_log<T>(phc);
+        pb[vv] = inr ? wv / p : T(0);
+        wsum += inr ? wv : T(0);
+      }
+      s_llw += (double)llw;
+      const T cn = wsum * ips;                          // d/dp_v' of -sum_v w_v log(sum p): the same for every v'
+      for (int k = 0; k < K; ++k) {
+        T sv = 0, rowsum = 0;
+        for (int vv = 0; vv < V; ++vv) { sv += phiS[k * V + vv] * pb[vv]; rowsum += phiS[k * V + vv]; }
+        locbar[(int64_t)k * ldk + n] = sv - cn * rowsum;
+      }
+      // the Phi gradient's constant part: theta_k (pbar_v - cn)
+      for (int vv = 0; vv < V; ++vv) pb[vv] -= cn;
+    } else {
+      for (int k = 0; k < K; ++k) th[k] = 0;
+      for (int vv = 0; vv < V; ++vv) pb[vv] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * V; e += RB) {
+      const int k = e / V, vv = e - k * V;
+      T sacc = 0;
+      for (int r = 0; r < RB; ++r) sacc += thS[r * (K + 1) + k] * pbS[r * (V + 1) + vv];
+      accS[e] += sacc;
+    }
+    __syncthreads();
+  }
+  if (phase == 0) return;
+  if (phase == 1) {
+    const double b1 = block_sum(s_llw, scratch);
+    if (threadIdx.x == 0) dpart[4 * (int64_t)blockIdx.x + 1] = b1;
+    for (int e = threadIdx.x; e < K * V; e += RB) phibar_part[(int64_t)blockIdx.x * K * V + e] = accS[e];
+  } else {
+    const double b0 = block_sum(s_site, scratch), b2 = block_sum(s_noise, scratch), b3 = block_sum(s_vd, scratch);
+    if (threadIdx.x == 0) {
+      dpart[4 * (int64_t)blockIdx.x + 0] = b0; dpart[4 * (int64_t)blockIdx.x + 2] = b2; dpart[4 * (int64_t)blockIdx.x + 3] = b3;
+    }
+  }
+}
+
 // The same per-row terms when the guide and the model evaluate the GP predictive at DIFFERENT inputs - the reference's quirk Q3
 // (gdrf/models/sparse_gdrf.py:376-380: for a world other than the unit cube the guide scales its inputs twice, the model once).
 // Guide side (subscript g): mu = loc_g + v_g eps, log q = -log v_g - eps^2 / 2.  Model side (m): log p = -log s_m - (d / s_m)^2 / 2 with

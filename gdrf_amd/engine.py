@@ -99,6 +99,9 @@ class Engine:
         self._guess_level: Optional[int] = None      # jitter level of the previous step: this step starts on it speculatively
         self._probe_stream = torch.cuda.Stream(device=self.device)
         self.speculate = True
+        # a caller-supplied link (the reference's `link_function`, abstract_gdrf.py:34-50): a callable on the (K, n) tensor mu returning the
+        # (K, n) topic weights; None = the softmax link fused into the row kernel.  Evaluated with torch between three library calls.
+        self.link_function = None
 
     def __del__(self):
         try:
@@ -382,7 +385,11 @@ class Engine:
         Ts, ds = [], []
         xg = getattr(self, "_xs_guide", None)
         for p in range(P):
-            if xg is None:
+            if self.link_function is not None:
+                if xg is not None:
+                    raise NotImplementedError("a custom link_function together with a non-unit world's doubly scaled guide (quirk Q3)")
+                self._step_local_link(xs, ws, eps[p], n, s)
+            elif xg is None:
                 _lib.check(self.lib.gdrf_step_local(self.ctx, xs.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n, self.Z.data_ptr(),
                                                     self.params.data_ptr(), self.red_T.data_ptr(), self.red_d.data_ptr(), s),
                            "gdrf_step_local")
@@ -417,6 +424,27 @@ class Engine:
             dist.all_reduce(self.red_T, group=pg)    # RCCL over xGMI (backend "nccl" on ROCm)
             _lib.check(self.lib.gdrf_payload_unpack(self.ctx, self.red_T.data_ptr(), self.red_d.data_ptr(), s), "gdrf_payload_unpack")
         self._finish(ng, None)
+
+    def _step_local_link(self, xs, ws, eps_p, n: int, s: int):
+        """gdrf_step_local with the link and its Jacobian evaluated here: theta = link(mu) and mubar = J^T thetabar by autograd
+        (sparse_gdrf.py:361: `topic_probs = self._link_function(mu).transpose(-2, -1)`)."""
+        args = (self.ctx, xs.data_ptr(), ws.data_ptr(), eps_p.data_ptr(), n, self.Z.data_ptr(), self.params.data_ptr(),
+                self.red_T.data_ptr(), self.red_d.data_ptr(), s)
+        _lib.check(self.lib.gdrf_step_local_link(*args, 0, None, 0), "gdrf_step_local_link(0)")
+        mu = self.workspace("mu", n).requires_grad_(True)                      # (K, n)
+        with torch.enable_grad():
+            theta = self.link_function(mu)
+        if tuple(theta.shape) != (self.K, n):
+            raise ValueError(f"link_function returned shape {tuple(theta.shape)}, expected ({self.K}, {n}) like its argument")
+        th = theta.detach().to(self.dtype).contiguous()
+        _lib.check(self.lib.gdrf_step_local_link(*args, 1, th.data_ptr(), n), "gdrf_step_local_link(1)")
+        thbar = self.workspace("locbar", n)
+        if theta.requires_grad:
+            (mubar,) = torch.autograd.grad(theta, mu, grad_outputs=thbar.to(theta.dtype))
+        else:                                                                  # a link that ignores mu
+            mubar = torch.zeros_like(mu)
+        mubar = mubar.detach().to(self.dtype).contiguous()
+        _lib.check(self.lib.gdrf_step_local_link(*args, 2, mubar.data_ptr(), n), "gdrf_step_local_link(2)")
 
     def _distributed(self) -> bool:
         if self.pg is None:

@@ -97,9 +97,12 @@ class SparseMultinomialGDRF:
         guide_rescale: bool = True,
         **kwargs,
     ):
-        if link_function is not None:
-            raise NotImplementedError("custom link_function: the HIP path fuses the softmax link and its Jacobian "
-                                      "(gdrf/models/abstract_gdrf.py:21-22)")
+        if link_function is not None and not callable(link_function):
+            raise TypeError("link_function must be callable")
+        # abstract_gdrf.py:34-50: None = softmax over the topics (fused into the row kernel).  A callable maps the (K, N) tensor mu to
+        # (K, N) topic weights; the step then evaluates it (and its Jacobian, by autograd) with torch between three library calls
+        # (gdrf_step_local_link), and the predictive methods apply it to log_topic_probs as abstract_gdrf.py:113-119,137-139 do.
+        self._link_function = link_function
         if mean_function is not None and not callable(mean_function):
             raise TypeError("mean_function must be callable")
         if randomize_metric is not None and not callable(randomize_metric):
@@ -171,6 +174,7 @@ class SparseMultinomialGDRF:
                      learn_inducing=not self._fixed_inducing_points, whiten=self._whiten)
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
+        new.link_function = self._link_function
         if e is None:
             self._engine = new                  # a randomize_metric may already call the model's methods
             self._init_params(new)
@@ -288,10 +292,14 @@ class SparseMultinomialGDRF:
         return self._engine_for(1).predict(xs_s, 0)
 
     def topic_probs(self, xs) -> torch.Tensor:
+        if self._link_function is not None:                  # abstract_gdrf.py:113-115
+            return self._link_function(self.log_topic_probs(xs)).T
         xs_s, _ = self._prepare_inputs(xs)
         return self._engine_for(1).predict(xs_s, 1)
 
     def word_probs(self, xs) -> torch.Tensor:
+        if self._link_function is not None:                  # abstract_gdrf.py:117-119
+            return self.topic_probs(xs) @ self.word_topic_matrix
         xs_s, _ = self._prepare_inputs(xs)
         return self._engine_for(1).predict(xs_s, 2)
 
@@ -303,6 +311,9 @@ class SparseMultinomialGDRF:
 
     def perplexity(self, x, w) -> torch.Tensor:
         """exp(-sum w log p / sum w): abstract_gdrf.py:137-139, as a 0-d tensor (train_script.py:469-472 calls .item())."""
+        if self._link_function is not None:                  # abstract_gdrf.py:137-139, literally
+            wd = torch.as_tensor(w).to(self.device)
+            return ((wd * self.word_probs(x).log()).sum() / -wd.sum()).exp()
         xs_s, ws_d = self._prepare_inputs(x, w)
         s = self._engine_for(1).predict(xs_s, 3, ws_d)
         return torch.exp(-s[0] / s[1])

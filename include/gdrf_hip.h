@@ -141,6 +141,15 @@ int gdrf_factorize(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, dou
 int gdrf_step_local(gdrf_ctx* ctx, const void* X_dev, const int32_t* ws_dev, const void* eps_dev, int64_t n_local,
                     const void* Z_dev, const void* params_dev, void* red_T_dev, double* red_d_dev, void* stream);
 
+/* One step around a caller-supplied link function (the reference's `link_function` constructor argument, gdrf/models/abstract_gdrf.py:34-50,
+ * used as `self._link_function(mu).transpose(-2, -1)` in gdrf/models/sparse_gdrf.py:361), which the caller evaluates itself between three calls:
+ *   phase 0: everything of gdrf_step_local up to mu = f_loc + f_var eps (+ mean) -> workspace 14 (K, ldk);
+ *   phase 1: ext = theta = link(mu), (K, ext_ld) -> d loglik / d theta in workspace 6, the word-topic gradient and the log-likelihood sum;
+ *   phase 2: ext = mubar = J_link^T thetabar, (K, ext_ld) -> the Normal sites, the row-local backward and the rest of gdrf_step_local.
+ * theta need not sum to one over the topics (Multinomial normalises p = theta^T Phi, as torch does).  Not a fused path. */
+int gdrf_step_local_link(gdrf_ctx* ctx, const void* xs_dev, const int32_t* ws_dev, const void* eps_dev, int64_t n_local, const void* Z_dev,
+                         const void* params_dev, void* red_T_dev, double* red_d_dev, void* stream, int phase, const void* ext_dev, int64_t ext_ld);
+
 /* The same with the guide and the model evaluated at DIFFERENT inputs: the reference's guide scales its inputs twice
  * (gdrf/models/sparse_gdrf.py:376 @scale_decorator and :380 `xs = self.scale(xs)`), its model once (:324), so for a world other
  * than the unit cube the guide's gp.util.conditional sees X_guide = scale(scale(xs)) and the model's X_model = scale(xs).

@@ -171,7 +171,7 @@ class RefShapedGDRF:
                  Z: Optional[torch.Tensor] = None, optimizer="adam", lr=1e-3,
                  force_jitter_level: Optional[int] = None, learn_inducing: bool = False, scale_mixture: float = 1.0,
                  whiten: bool = True, mean_function=None, world: Optional[Sequence[Tuple[float, float]]] = None,
-                 guide_rescale: bool = True):
+                 guide_rescale: bool = True, link_function=None):
         self.dtype = dtype
         # topic_model.py:148-198: inputs are mapped to the unit cube by (x - lower) / delta.  With world=None the inputs are taken as
         # already scaled (what train() builds: world = [(0, 1)]^D, train_script.py:261-271).  Quirk Q3 (sparse_gdrf.py:376-380): the
@@ -180,6 +180,8 @@ class RefShapedGDRF:
         self.world = None if world is None else [(float(a), float(b)) for a, b in world]
         self.guide_rescale = bool(guide_rescale)
         self.mean_function = mean_function          # abstract_gdrf.py:33-48; None = zero_mean (abstract_gdrf.py:17-18)
+        # abstract_gdrf.py:34-50: None = softmax_link_function (abstract_gdrf.py:21-22: softmax over dim -2)
+        self.link_function = (lambda x: torch.softmax(x, -2)) if link_function is None else link_function
         self.kind = kind
         self.K = K
         self.xs = torch.as_tensor(xs).to(dtype)
@@ -284,7 +286,7 @@ class RefShapedGDRF:
             f_loc2 = f_loc2 + self.mean_function(xs)      # sparse_gdrf.py:346
         lp_mu = Normal(f_loc2, f_var2 + c["noise"]).log_prob(mu).sum()
         lp_phi = Dirichlet(self.alpha).log_prob(c["phi"]).sum()
-        topic_probs = torch.softmax(mu, -2).transpose(-2, -1)
+        topic_probs = self.link_function(mu).transpose(-2, -1)          # sparse_gdrf.py:361
         probs = torch.matmul(topic_probs, c["phi"])
         ll = Multinomial(probs=probs, validate_args=False).log_prob(ws).sum()
         elbo = scale * (lp_mu + lp_phi + ll - lq_mu)
@@ -308,7 +310,7 @@ class RefShapedGDRF:
         mu = f_loc + f_var * eps
         lq_mu = Normal(f_loc, f_var).log_prob(mu).sum()
         lp_mu = Normal(f_loc, f_var + c["noise"]).log_prob(mu).sum()
-        probs = torch.matmul(torch.softmax(mu, -2).transpose(-2, -1), c["phi"])
+        probs = torch.matmul(self.link_function(mu).transpose(-2, -1), c["phi"])
         ll = Multinomial(probs=probs, validate_args=False).log_prob(ws).sum()
         return lp_mu + ll - lq_mu
 
@@ -390,7 +392,7 @@ class RefShapedGDRF:
         return f_loc
 
     def topic_probs(self, xs=None):
-        return torch.softmax(self.log_topic_probs(xs), -2).T
+        return self.link_function(self.log_topic_probs(xs)).T            # abstract_gdrf.py:113-115
 
     def word_probs(self, xs=None):
         return self.topic_probs(xs) @ self.constrained()["phi"].detach()

@@ -381,3 +381,91 @@ def test_three_dimensional_inputs_fp32_and_predictive():
     tp = eng.predict(xs, 1).cpu().double().numpy()                      # topic_probs (n, K)
     with torch.no_grad():
         assert np.abs(tp - m64.topic_probs(m.xs.double()).numpy()).max() < 1e-4
+
+
+_LINKS = {
+    "tempered_softmax": lambda mu: torch.softmax(0.5 * mu, -2),                     # sums to one over the topics
+    "sigmoid": lambda mu: 0.05 + torch.sigmoid(0.02 * mu),                          # does not: Multinomial normalises theta^T Phi.  (mu = f_loc +
+                                                                                    # f_var eps spans +-1e3 here: a bare sigmoid is 0 for every topic of some rows in float32)
+    "smoothed_softmax": lambda mu: (torch.softmax(mu, -2) + 0.1) / (1.0 + 0.1 * mu.shape[-2]),          # a floor under every topic
+}
+
+
+@pytest.mark.parametrize("link", sorted(_LINKS))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_custom_link_function_matches_autograd(link, dtype):
+    """The reference's `link_function` argument (abstract_gdrf.py:34-50, sparse_gdrf.py:361): the link and its Jacobian are evaluated with
+    torch between the three phases of gdrf_step_local_link.  Loss and every gradient against the oracle with the same callable."""
+    from oracle.gdrf_oracle import RefShapedGDRF
+    from gdrf_amd.data import synth_circles
+    xs, ws, _ = synth_circles(17, 9, 13, 4, seed=4)
+    m = RefShapedGDRF(xs, ws, kind="rbf", K=4, n_points=(4, 3), lengthscale=0.2, dtype=torch.float64, jitter=1e-6 if dtype == torch.float64 else 1e-4,
+                      link_function=_LINKS[link], optimizer="adam", lr=1e-2)
+    g = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64))
+        m.params["u_scale_tril_unc"].add_(0.1 * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril())
+        m.params["phi_unc"].add_(0.5 * torch.randn(m.params["phi_unc"].shape, generator=g, dtype=torch.float64))
+        if dtype == torch.float32:
+            for p in m.params.values():
+                p.copy_(p.float().double())
+    eps = torch.randn(4, m.N, generator=g, dtype=torch.float64).to(dtype).double()
+    eng = engine_from_oracle(m, dtype=dtype)
+    eng.link_function = _LINKS[link]
+    xs_d, ws_d = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+    eng.loss_and_grads(xs_d, ws_d, dev(eps, eng))
+    out = eng.read_out()
+    assert out["chol_failed"] == 0
+    m.force_jitter_level = eng.last_jitter_level
+    loss_ref, grads_ref = m.loss_and_grads(eps, xs=m.xs.to(dtype).double())
+    tol_l, tol_g = (LOSS_TOL_VS_TORCH, 1e-7) if dtype == torch.float64 else (1e-4, 2e-2)
+    assert abs(out["loss"] - loss_ref) <= tol_l * abs(loss_ref), (out["loss"], loss_ref)
+    gv = eng.named_views(eng.grads)
+    for name in eng.PARAM_NAMES:
+        assert relerr(gv[name].cpu().double().numpy(), grads_ref[name].numpy()) < tol_g, name
+    if dtype == torch.float64:                      # and a few optimizer steps stay on the oracle's trajectory
+        for step in range(3):
+            e = torch.randn(4, m.N, generator=g, dtype=torch.float64)
+            loss_ref = m.step(e)
+            eng.loss_and_grads(xs_d, ws_d, dev(e, eng))
+            eng.adam("adam", 1e-2)
+            assert np.isfinite(loss_ref) and abs(eng.read_out()["loss"] - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref), step
+        for name in eng.PARAM_NAMES:
+            ref_p = m.params[name].detach().numpy()
+            assert np.isfinite(ref_p).all() and relerr(eng.view(name).cpu().numpy(), ref_p) < 1e-7, name
+
+
+def test_custom_link_function_through_the_model_surface():
+    """SparseMultinomialGDRF(link_function=...) + SVI.step, and the predictive helpers of abstract_gdrf.py:113-139 with that link."""
+    from gdrf_amd.data import synth_circles
+    from gdrf_amd.infer import SVI, Trace_ELBO
+    from gdrf_amd.kernels import RBF
+    from gdrf_amd.models import SparseMultinomialGDRF
+    from gdrf_amd.optim import Adam
+    from gdrf_amd import poutine
+    from oracle.gdrf_oracle import RefShapedGDRF
+    link = _LINKS["tempered_softmax"]
+    xs_np, ws_np, _ = synth_circles(14, 10, 9, 3, seed=8)
+    xs = torch.from_numpy(xs_np).to("cuda:0", torch.float64); ws = torch.from_numpy(ws_np).to("cuda:0")
+    model = SparseMultinomialGDRF(xs=xs, ws=ws, world=[(0.0, 1.0)] * 2, kernel=RBF(input_dim=2, lengthscale=torch.tensor(0.2), variance=torch.tensor(25.0)),
+                                  num_observation_categories=9, num_topic_categories=3, dirichlet_param=0.01, n_points=[4, 3],
+                                  fixed_inducing_points=True, inducing_init="grid", maxjitter=15, jitter=1e-6, device="cuda:0",
+                                  dtype=torch.float64, seed=3, link_function=link)
+    scale = poutine.scale(scale=1.0 / xs.shape[0])
+    svi = SVI(model=scale(model.model), guide=scale(model.guide), optim=Adam({"lr": 1e-2}), loss=Trace_ELBO(num_particles=1))
+    ref = RefShapedGDRF(xs_np, ws_np, kind="rbf", K=3, n_points=(4, 3), lengthscale=0.2, dtype=torch.float64, jitter=1e-6, link_function=link,
+                        optimizer="adam", lr=1e-2)
+    eng = model._engine_for(xs.shape[0])
+    g = torch.Generator().manual_seed(31)
+    for step in range(3):
+        e = torch.randn(3, xs.shape[0], generator=g, dtype=torch.float64)
+        loss = svi.step(xs=xs, ws=ws, subsample=False, eps=e)
+        ref.force_jitter_level = eng.last_jitter_level
+        loss_ref = ref.step(e)
+        assert abs(loss - loss_ref) <= LOSS_TOL_VS_TORCH * abs(loss_ref), (step, loss, loss_ref)
+    with torch.no_grad():
+        tp = model.topic_probs(xs).cpu().numpy()
+        assert tp.shape == (xs.shape[0], 3)
+        assert np.abs(tp - ref.topic_probs(torch.from_numpy(xs_np).double()).numpy()).max() < 1e-8
+        ppx = float(model.perplexity(xs, ws))
+        assert abs(ppx - float(ref.perplexity(torch.from_numpy(xs_np).double(), torch.from_numpy(ws_np)))) < 1e-6 * ppx

@@ -93,8 +93,8 @@ def test_model_rejects_options_outside_the_hot_path_before_touching_the_gpu():
     k = RBF(2, lengthscale=torch.tensor(0.1), variance=torch.tensor(25.0))
     base = dict(num_observation_categories=5, num_topic_categories=2, world=[(0.0, 1.0)] * 2, kernel=k, dirichlet_param=0.01,
                 n_points=[3, 3], fixed_inducing_points=True)
-    with pytest.raises(NotImplementedError):
-        SparseMultinomialGDRF(**{**base, "link_function": lambda x: x})
+    with pytest.raises(TypeError):
+        SparseMultinomialGDRF(**{**base, "link_function": "softmax"})          # a callable is accepted (gdrf_step_local_link); anything else is not
     with pytest.raises(TypeError):
         SparseMultinomialGDRF(**{**base, "mean_function": 1.0})
     with pytest.raises(TypeError):
