@@ -721,7 +721,7 @@ template <typename T, typename TS> struct Impl {
 #define GDRF_K64(X) { HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_f16_k64_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64)); \
                       hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel<X>, dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds64, s, a); }
             if (abl == 1) GDRF_K64(1) else if (abl == 2) GDRF_K64(2) else if (abl == 3) GDRF_K64(3) else if (abl == 4) GDRF_K64(4)
-            else if (abl == 7) GDRF_K64(7) else GDRF_K64(0)
+            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else GDRF_K64(0)
 #undef GDRF_K64
           }
         } else if (!(alt && alt[0] == '1') && lds_cc <= 160 * 1024) {

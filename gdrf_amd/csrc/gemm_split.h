@@ -828,8 +828,18 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
             else P[a] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], (ks == 0 && t == 0) ? f32x4{0, 0, 0, 0} : P[a]);
           }
       // the next chunk's requests, one or two behind each column group's MFMAs (an LDS-DMA instruction stalls its wave at issue)
-      if (more && !(ABL & 2)) dma_b1(c + 1, b >> 1, b & 1);
-      if (more_a && !(ABL & 2)) { dma_a1(q + 1, b >> 1, 0, b & 1); dma_a1(q + 1, b >> 1, 1, b & 1); }
+      if (ABL & 8) {
+        // staggered requests: the two waves of a SIMD belong to different groups; group 0 issues all its requests behind b = 0, 1 and
+        // group 1 behind b = 2, 3, so that one wave's issue stalls run under the other's MFMAs instead of both stalling together
+        const int bb = gp ? b - 2 : b;
+        if (bb >= 0 && bb < 2) {
+          if (more) { dma_b1(c + 1, bb, 0); dma_b1(c + 1, bb, 1); }
+          if (more_a) { dma_a1(q + 1, bb, 0, 0); dma_a1(q + 1, bb, 1, 0); dma_a1(q + 1, bb, 0, 1); dma_a1(q + 1, bb, 1, 1); }
+        }
+      } else {
+        if (more && !(ABL & 2)) dma_b1(c + 1, b >> 1, b & 1);
+        if (more_a && !(ABL & 2)) { dma_a1(q + 1, b >> 1, 0, b & 1); dma_a1(q + 1, b >> 1, 1, b & 1); }
+      }
       if (!(ABL & 1)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
