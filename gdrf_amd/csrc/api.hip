@@ -718,11 +718,24 @@ template <typename T, typename TS> struct Impl {
             const size_t lds64 = 8 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb;
             const char* ab = getenv("GDRF_WBAR_ABLATE");         // timing-only diagnostic variants (wrong results)
             const int abl = ab ? atoi(ab) : 0;
+            // few rows (streaming mini-batches): a handful of workgroups would each walk all K x Mp / 64 chunks one after the other
+            // (0.19 ms at n = 64); the reduction blocks are split over gridDim.y slices into slabs, summed in a fixed order
+            const int nkb = Mp / 64;
+            static const bool wsplit = !(getenv("GDRF_WBAR_SLICES") && getenv("GDRF_WBAR_SLICES")[0] == '0');
+            int nslice = 1;
+            if (wsplit && pairs * nct_ <= 32 && nkb >= 2 && !abl) nslice = std::min(nkb, 8);
+            if ((size_t)nslice * n * Mp * sizeof(float) > (size_t)c->nsplit_cap * (K + 1) * Mp * Mp * sizeof(float)) nslice = 1;   // the TN slab buffer is idle now
+            if (nslice > 1) { a.slab = (float*)c->slab; a.slab_stride = (int64_t)round_up(n, 256) * Mp; a.nslice = nslice; }
 #define GDRF_K64(X) { HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_f16_k64_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64)); \
-                      hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel<X>, dim3((unsigned)round_up(pairs * nct_, 8)), dim3(512), lds64, s, a); }
+                      hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel<X>, dim3((unsigned)round_up(pairs * nct_, 8), (unsigned)nslice), dim3(512), lds64, s, a); }
             if (abl == 1) GDRF_K64(1) else if (abl == 2) GDRF_K64(2) else if (abl == 3) GDRF_K64(3) else if (abl == 4) GDRF_K64(4)
             else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else GDRF_K64(0)
 #undef GDRF_K64
+            if (nslice > 1) {
+              const int64_t n4 = n * Mp / 4;
+              hipLaunchKernelGGL(wbar_slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)a.slab, a.slab_stride, nslice, n4,
+                                 (float*)c->Wbar, a.wbar_max);
+            }
           }
         } else if (!(alt && alt[0] == '1') && lds_cc <= 160 * 1024) {
           HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_split_cc_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cc));

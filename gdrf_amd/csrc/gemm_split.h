@@ -219,6 +219,9 @@ template <class SP> struct BwdWbarSplitArgs {
   const float* sc;                             // block scales (SplitLay)
   unsigned* wbar_max;                          // max |Wbar| (bits), for the scale of the G^T contraction's operand
   unsigned long long* stamps = nullptr;        // diagnostic builds only (STAMP)
+  // bwd_wbar_f16_k64_kernel only, few rows (mini-batches): gridDim.y = nslice slices of the reduction blocks, slice y writes its partial
+  // sum to slab + y * slab_stride (slice 0 carries the rank-K and the -2 a W terms); wbar_slab_sum_kernel adds them into Wbar
+  float* slab = nullptr; int64_t slab_stride = 0; int nslice = 1;
 };
 
 // NG = 1: one 256-thread workgroup per tile, two workgroups per CU (they share the CU's SIMDs at random).
@@ -764,7 +767,12 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
   const int drow = lane >> 2, dq = ((lane & 3) ^ split_swz(drow)) * 8;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned a_lds = lds_addr(As), b_lds = lds_addr(Bs);
-  const int nk = Mp / 64, nchunks = nk * K;                              // Mp % 64 == 0 (checked by the host)
+  const int nk = Mp / 64;                                               // Mp % 64 == 0 (checked by the host)
+  // this workgroup's reduction blocks [q_lo, q_hi): all of them, or slice blockIdx.y of nslice
+  const int q_lo = (int)(((int64_t)nk * blockIdx.y) / g.nslice), q_hi = (int)(((int64_t)nk * (blockIdx.y + 1)) / g.nslice);
+  const int c_lo = q_lo * K, nchunks = q_hi * K;
+  const bool first_slice = blockIdx.y == 0;
+  float* const out_base = g.nslice > 1 ? g.slab + (int64_t)blockIdx.y * g.slab_stride : g.Wbar;
   const int b_rbk = wave_u + 4 * gp, b_row = b_rbk * 16 + drow;
   const int b_col = (n0 + b_row < Mp) ? n0 + b_row : 0;
   // B chunk c = (block q, topic rep), k-step ks, piece p -> buffer c & 1: this wave (of 8) moves one 16-row block
@@ -783,12 +791,12 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int p = 0; p < NP; ++p) { dma_a1(0, ks, 0, p); dma_a1(0, ks, 1, p); dma_b1(0, ks, p); }
+    for (int p = 0; p < NP; ++p) { dma_a1(q_lo, ks, 0, p); dma_a1(q_lo, ks, 1, p); dma_b1(c_lo, ks, p); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                        // also publishes the scale table
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = c_lo; c < nchunks; ++c) {
     const int q = c / K, rep = c - q * K;
-    const bool more = c + 1 < nchunks, more_a = rep == 1 && q + 1 < nk;   // A(q + 1) into the image whose fragments were read one phase ago
+    const bool more = c + 1 < nchunks, more_a = rep == 1 && q + 1 < q_hi;   // A(q + 1) into the image whose fragments were read one phase ago
     const E* Bb = Bs + (c & 1) * 2 * IMG;
     if (rep == 0) {
 #pragma unroll
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
   }
   // rank-K epilogue term locbar^T U on the native f32 matrix instruction (exact f32, no split, no range question): lane
   // (lr, lg) supplies A[row lr][k = lg] and B[k = lg][col lr] of v_mfma_f32_16x16x4_f32, whose C/D layout is the accumulators'
-  for (int k0 = 0; k0 < K; k0 += 4) {
+  for (int k0 = 0; k0 < (first_slice ? K : 0); k0 += 4) {
     const int k = k0 + lg;
     float av[4], bv[4];
 #pragma unroll
@@ -900,18 +908,18 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
         const int n = n0 + wc * 64 + cv;
         const f32x4 t = *reinterpret_cast<const f32x4*>(tile + rr * TS + cv);
         if (m < g.nrows && n < Mp) {                         // Mp is a multiple of 32: a float4 never straddles the edge
-          const float as2 = 2.0f * g.asum[m];
+          const float as2 = first_slice ? 2.0f * g.asum[m] : 0.0f;
           const f32x4 w = *reinterpret_cast<const f32x4*>(g.W + m * Mp + n);
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o[e] = t[e] - as2 * w[e]; wmax = fmaxf(wmax, fabsf(o[e])); }
-          *reinterpret_cast<f32x4*>(g.Wbar + m * Mp + n) = o;
+          *reinterpret_cast<f32x4*>(out_base + m * Mp + n) = o;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the tile is overwritten with the other half
     }
   }
-  if (g.wbar_max) {                                          // order-independent: the maximum of non-negative floats as integers
+  if (g.wbar_max && g.nslice == 1) {                         // order-independent: the maximum of non-negative floats as integers
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
     if (lane == 0 && wmax > 0.0f) atomicMax(g.wbar_max, __float_as_uint(wmax));
@@ -919,6 +927,29 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
 }
 
 
+
+// Wbar = the sum of the slices' partial sums (fixed order), and its maximum for the block scale of the G^T operand
+__global__ __launch_bounds__(256) void wbar_slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int nslice, int64_t n4 /*float4 count*/,
+                                                           float* __restrict__ Wbar, unsigned* __restrict__ wbar_max) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float wmax = 0.0f;
+  if (i < n4) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(slab + 4 * i);
+    for (int sl = 1; sl < nslice; ++sl) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(slab + (int64_t)sl * slab_stride + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += t[e];
+    }
+    *reinterpret_cast<f32x4*>(Wbar + 4 * i) = acc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wmax = fmaxf(wmax, fabsf(acc[e]));
+  }
+  if (wbar_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && wmax > 0.0f) atomicMax(wbar_max, __float_as_uint(wmax));
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // tt[k][n] = || S_k^T w_n ||^2 on the same emulation: T_k = W S_k lives only in the accumulators; a row tile and topic walk

@@ -469,3 +469,32 @@ def test_custom_link_function_through_the_model_surface():
         assert np.abs(tp - ref.topic_probs(torch.from_numpy(xs_np).double()).numpy()).max() < 1e-8
         ppx = float(model.perplexity(xs, ws))
         assert abs(ppx - float(ref.perplexity(torch.from_numpy(xs_np).double(), torch.from_numpy(ws_np)))) < 1e-6 * ppx
+
+
+@pytest.mark.parametrize("shape", [(20, 15, (16, 12)), (8, 8, (32, 16))])
+def test_wbar_reduction_slices_for_few_rows(shape):
+    """Mini-batch sizes: bwd_wbar_f16_k64_kernel splits its reduction blocks over gridDim.y slices into slabs (a handful of workgroups would
+    otherwise walk all K x Mp / 64 chunks serially) and wbar_slab_sum_kernel adds them and takes the maximum that scales the G^T operand.
+    Wbar and G^T against fp64 products of the engine's own float32 inputs; bit-identical on a second call."""
+    W_, H_, npts = shape
+    m, eps = make_oracle(dtype=torch.float32, jitter=1e-4, kind="rbf", W=W_, H=H_, V=12, K=5, n_points=npts, lengthscale=0.1)
+    eng = engine_from_oracle(m, mfma_mode="f16x3")
+    xs, ws, e = dev(m.xs, eng), dev(m.ws, eng, torch.int32), dev(eps, eng)
+    eng.loss_and_grads(xs, ws, e)
+    n = m.N
+    Wm = eng.workspace("W", n).cpu().double().numpy()
+    vbar = eng.workspace("vbar", n).cpu().double().numpy()
+    locbar = eng.workspace("locbar", n).cpu().double().numpy()
+    asum = eng.workspace("asum", n).cpu().double().numpy()
+    S = eng.workspace("S").cpu().double().numpy()
+    U = eng.view("u_loc").cpu().double().numpy()
+    ref = locbar.T @ U - 2 * asum[:, None] * Wm
+    for k in range(m.K):
+        ref += (2 * vbar[k])[:, None] * (Wm @ (S[k] @ S[k].T))
+    got = eng.workspace("Wbar", n).cpu()
+    assert relerr(got.double().numpy(), ref) < 2e-5
+    Mp, lay = (m.M + 31) // 32 * 32, eng.red_layout
+    GT = eng.red_T[lay["GT"]:lay["GT"] + Mp * Mp].view(Mp, Mp)[:m.M, :m.M].cpu().double().numpy()
+    assert relerr(GT, Wm.T @ got.double().numpy()) < 2e-5
+    eng.loss_and_grads(xs, ws, e, force_level=eng.last_jitter_level)
+    assert torch.equal(eng.workspace("Wbar", n).cpu(), got)
