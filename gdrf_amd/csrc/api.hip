@@ -48,7 +48,7 @@ struct gdrf_ctx {
   int nt;                     // 128-wide tiles over Mp
   int nsplit_cap;
   // solve precision, M x M (ld Mp)
-  void *mmslab;               // [8][Mp][Mp] solve precision: split-K slabs of the single M x M products
+  void *mmslab; size_t mmslab_bytes;    // split-K slabs of the small M x M products: [slices][batch][Mp][Mp]
   void *Kuu, *Lw, *Lo, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *Zs, *GTs;      // Lo: the panel-wise factorisation's output (Lw is its work matrix)
   void *Knm;                  // [ncap][Mp] K_nm in the solve precision (forward A operand, backward epilogue)
   // probe (N-side precision) scratch, only when T != TS
@@ -236,7 +236,9 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   };
   int rc = 0;
 #define AL(ptr, bytes) if ((rc = A((void**)&(ptr), (bytes)))) { gdrf_ctx_destroy(c); return rc; }
-  AL(c->Kuu, mms) AL(c->Lw, mms) AL(c->Lo, mms) AL(c->mmslab, 8 * mms) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
+  AL(c->Kuu, mms) AL(c->Lw, mms) AL(c->Lo, mms)
+  c->mmslab_bytes = 8 * mms;
+  AL(c->mmslab, c->mmslab_bytes) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
   AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->ssz)
   AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
   AL(c->Cf, (size_t)K * M * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
@@ -450,19 +452,23 @@ template <typename T, typename TS> struct Impl {
   static int mm_nt(gdrf_ctx* c, const E* A, int64_t abs_, const E* Bt, int64_t bbs, E* Cm, int64_t cbs, E alpha, int batch,
                    hipStream_t s) {
     // a single M x M product is 16 workgroups of the NT core (45 us at M = 512 in double, four of them in a row in every step's
-    // Cholesky backward): split its reduction over 8 slices into slabs and add them (in double, fixed order)
+    // Cholesky backward), a batch of K = 10 is 160 (one per CU for the whole reduction): the reduction is split over S slices into
+    // slabs, which are added in double in a fixed order.  S: 8 for a single product, 4 for small batches.
     static const bool splitk = !(getenv("GDRF_MM_SPLITK") && getenv("GDRF_MM_SPLITK")[0] == '0');
-    const int S = 8, kw = c->Mp / S;
-    if (batch == 1 && splitk && c->mmslab && c->Mp >= 256 && c->Mp % S == 0 && kw % NTCfg<E>::BK == 0) {
-      const int64_t mm = (int64_t)c->Mp * c->Mp;
-      MMProb<E> p{{}, {}, {}, A, 0, Bt, 0, (E*)c->mmslab, mm, c->Mp, alpha, kw};
-      dim3 grid(c->nt * nct<E>(c), S);
+    const int64_t mm = (int64_t)c->Mp * c->Mp;
+    const int tiles = c->nt * nct<E>(c);
+    const int S = batch == 1 ? 8 : 4, kw = c->Mp / S;
+    // (batches: measured SLOWER - 160 workgroups already fill most CUs and the slab sum of K matrices costs more than the split saves)
+    if (splitk && batch == 1 && c->mmslab && tiles * batch <= 256 && c->Mp >= 256 && c->Mp % S == 0 && kw % NTCfg<E>::BK == 0 &&
+        (size_t)S * batch * mm * sizeof(E) <= c->mmslab_bytes) {
+      MMProb<E> p{{}, {}, {}, A, abs_, Bt, bbs, (E*)c->mmslab, mm, c->Mp, alpha, kw, batch};
+      dim3 grid(tiles, S * batch);
       hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
-      hipLaunchKernelGGL(reduce_slabs_kernel<E>, dim3((c->Mp + 255) / 256, c->Mp, 1), dim3(256), 0, s, (const E*)c->mmslab, S, 1, c->Mp, 0, Cm, GDRF_TILE / 2);
+      hipLaunchKernelGGL(reduce_slabs_kernel<E>, dim3((c->Mp + 255) / 256, c->Mp, batch), dim3(256), 0, s, (const E*)c->mmslab, S, batch, c->Mp, 0, Cm, GDRF_TILE / 2);
       LAUNCHCHK("mm_nt split-K");
       return 0;
     }
-    MMProb<E> p{{}, {}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha, 0};
+    MMProb<E> p{{}, {}, {}, A, abs_, Bt, bbs, Cm, cbs, c->Mp, alpha, 0, 1};
     dim3 grid(c->nt * nct<E>(c), batch);
     hipLaunchKernelGGL((gemm_nt_kernel<E, MMProb<E>>), grid, dim3(256), NTCfg<E>::LDS_BYTES, s, p);
     LAUNCHCHK("mm_nt");

@@ -662,24 +662,25 @@ template <typename T> struct MMProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   const T* Bt; int64_t b_bs;
   T* C; int64_t c_bs;
   int Mp; T alpha;
-  int kw;                          // > 0: split-K - "batch" bz is a slice [bz kw, (bz + 1) kw) of the reduction (a_bs = b_bs = 0, C = slabs)
+  int kw;                          // > 0: split-K - the grid's y index is (slice * nb + batch): slice [s kw, (s + 1) kw) of the reduction of batch
+  int nb;                          //      member `batch`; C = slabs [slice][batch][Mp][Mp] (c_bs = Mp * Mp), summed by reduce_slabs_kernel
   struct ACtx { int64_t m0; }; struct ECtx {};
   __device__ __forceinline__ int col_tiles() const { return (Mp + NTCfg<T>::CW - 1) / NTCfg<T>::CW; }
   __device__ __forceinline__ bool loop_cols() const { return false; }
   __device__ __forceinline__ int a_reuse() const { return 1; }
   __device__ __forceinline__ void krange(int64_t, int, int bz, int& kb, int& ke) const {
-    if (kw > 0) { kb = bz * kw; ke = (kb + kw < Mp) ? kb + kw : Mp; } else { kb = 0; ke = Mp; }
+    if (kw > 0) { kb = (bz / nb) * kw; ke = (kb + kw < Mp) ? kb + kw : Mp; } else { kb = 0; ke = Mp; }
   }
   __device__ __forceinline__ void prepA(ACtx& c, int64_t m0, int, char*) const { c.m0 = m0; }
   __device__ __forceinline__ void prepE(ECtx&, int64_t, int) const {}
   __device__ __forceinline__ V zero() const { V z; for (int e = 0; e < Vec16<T>::N; ++e) z[e] = 0; return z; }
   __device__ __forceinline__ V loadA(const ACtx& c, int i, int k, int, int bz) const {
     const int64_t r = c.m0 + nt_stage_row<T>(i);
-    return (r < Mp) ? *reinterpret_cast<const V*>(A + bz * a_bs + r * Mp + k) : zero();
+    return (r < Mp) ? *reinterpret_cast<const V*>(A + (kw > 0 ? bz % nb : bz) * a_bs + r * Mp + k) : zero();
   }
   __device__ __forceinline__ V loadB(int n0, int i, int k, int, int bz) const {
     const int c = n0 + nt_stage_row<T>(i);
-    return (c < Mp) ? *reinterpret_cast<const V*>(Bt + bz * b_bs + (int64_t)c * Mp + k) : zero();
+    return (c < Mp) ? *reinterpret_cast<const V*>(Bt + (kw > 0 ? bz % nb : bz) * b_bs + (int64_t)c * Mp + k) : zero();
   }
   template <class Acc, int NB_>
   __device__ __forceinline__ void tile_done(Acc (&acc)[4][NB_], int64_t m0, int n0, int bz, ECtx&, int wr, int wc, int lane) const {
