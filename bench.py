@@ -256,6 +256,7 @@ def main():
         tile_factor = {"fwd_t": 1.25, "tn_sym": 1.25, "fwd_w": 1.25, "bwd_knm": 1.25}
         if eng.mfma_mode == "f16x3":
             tile_factor["tn_sym"] = 1.0625       # tn_topics_f16_kernel skips 32 x 32 sub-tiles above the diagonal: 136 of 256 computed for 128 needed
+            tile_factor["fwd_t"] = 1.125         # fwd_t_split_q4_kernel: the triangle at 64-column granularity per wave
         dom = max(flops, key=lambda k: per_step[k])
         dom_t = ms[dom] * 1e-3
         f32_equiv = flops[dom] / dom_t / 1e12 if dom_t > 0 else 0.0
