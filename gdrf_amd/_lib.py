@@ -39,6 +39,7 @@ SIGNATURES = {
     "gdrf_probe_launch": (_int, [_vp, _vp, _vp, C.POINTER(_dbl), _int, _vp]),
     "gdrf_probe_read": (_int, [_vp, _int, C.POINTER(_int), _vp]),
     "gdrf_factorize": (_int, [_vp, _vp, _vp, _dbl, _vp]),
+    "gdrf_factorize_mode": (_int, [_vp, _vp, _vp, _dbl, _vp, _int]),
     "gdrf_step_local": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gdrf_step_local_link": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64]),
     "gdrf_step_local2": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

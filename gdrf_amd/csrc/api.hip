@@ -71,7 +71,8 @@ struct gdrf_ctx {
   double *llpart;             // per-workgroup partials of the data constant (own buffer: it may be queued beside a step)
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
   double* alpha_dev; double lgam_const;
-  Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[8..16): probe levels failed
+  Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[1]: a reused factorisation's inputs changed; flag[8..16): probe levels failed
+  void* snap; int prefact_valid; double prefact_jitter;     // the inputs of a factorisation made ahead of its step (gdrf_factorize_mode)
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
   hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join, ev_fact0, ev_fact;
   int fact_pending;           // a factorisation has been queued on the side stream: consumers wait for ev_fact
@@ -238,6 +239,8 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
 #define AL(ptr, bytes) if ((rc = A((void**)&(ptr), (bytes)))) { gdrf_ctx_destroy(c); return rc; }
   AL(c->Kuu, mms) AL(c->Lw, mms) AL(c->Lo, mms)
   c->mmslab_bytes = 8 * mms;
+  c->prefact_valid = 0; c->prefact_jitter = 0;
+  AL(c->snap, (size_t)(4 + (size_t)c->M * c->D) * c->esz)
   AL(c->mmslab, c->mmslab_bytes) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
   AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->ssz)
   AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
@@ -278,7 +281,17 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->hyp, sizeof(Hyper)) AL(c->hyp_probe, sizeof(Hyper)) AL(c->flag, 64)
   AL(c->ssc, (size_t)SplitLay{K}.nfloats() * sizeof(float)) AL(c->smx, (size_t)SplitLay{K}.nmax() * sizeof(unsigned))
 #undef AL
-  HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  {
+    // the side stream carries the factorisation chain (small launches the step's first GEMM waits for): highest priority, so that its
+    // workgroups are placed ahead of the K_nm kernel's 16 384 on the main stream (GDRF_SIDE_PRIO=0: default priority)
+    int least = 0, greatest = 0;
+    const char* sp = getenv("GDRF_SIDE_PRIO");
+    if (!(sp && sp[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+      HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, greatest));
+    } else {
+      HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    }
+  }
   for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact, &c->ev_wd})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(hipMemset(c->flag, 0, 64));
@@ -500,8 +513,20 @@ template <typename T, typename TS> struct Impl {
   // are refreshed on the caller's stream; the factorisation chain (one workgroup for most of its 1.7 ms) runs on the
   // context's side stream so that what follows on the caller's stream and does not need L (the S / B_k transforms and the
   // solve-precision K_nm of gdrf_step_local) overlaps it.  Every consumer of L calls join_fact() first.
-  static int factorize(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s) {
+  // mode 0: factorise.  mode 1: factorise AHEAD of the step that will use it (right behind the optimizer update, so that the chain runs while
+  // the host reads the loss and enqueues the next step) and keep a copy of its inputs.  mode 2: the step's own call - if a mode-1
+  // factorisation with this jitter is waiting, only compare its inputs with the current ones on the device (flag[1], read with the
+  // failure flag by gdrf_chol_failed: a mismatch makes the caller redo the step, like a wrong jitter guess); otherwise as mode 0.
+  static int factorize(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s, int mode = 0) {
     const int Mp = c->Mp, M = c->M;
+    const int64_t nzs = (int64_t)M * c->D;
+    if (mode == 2 && c->prefact_valid && jitter == c->prefact_jitter) {
+      hipLaunchKernelGGL(fact_snapshot_kernel<T>, dim3(1), dim3(256), 0, s, params, Z, nzs, P(c->snap), 1, c->flag + 1);
+      c->prefact_valid = 0;
+      LAUNCHCHK("factorize (reuse)");
+      return 0;
+    }
+    c->prefact_valid = 0;
     dim3 g2((Mp + 255) / 256, Mp);
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     const int64_t nz = (int64_t)M * c->D;
@@ -537,6 +562,10 @@ template <typename T, typename TS> struct Impl {
     }
     HIPCHK(hipEventRecord(c->ev_fact, f));
     c->fact_pending = 1;
+    if (mode == 1) {
+      hipLaunchKernelGGL(fact_snapshot_kernel<T>, dim3(1), dim3(256), 0, s, params, Z, nzs, P(c->snap), 0, (int*)nullptr);
+      c->prefact_valid = 1; c->prefact_jitter = jitter;
+    }
     LAUNCHCHK("factorize");
     return 0;
   }
@@ -770,7 +799,8 @@ template <typename T, typename TS> struct Impl {
     const int VE = Vec16<TS>::N;
     const int vpr = (c->Mp + VE - 1) / VE, rpp = vpr <= 256 ? 256 / vpr : 1;
     int64_t blocks = (n + 4 * rpp - 1) / (4 * rpp);
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    static const int64_t kcap = getenv("GDRF_KNM_SOLVE_BLOCKS") ? atoll(getenv("GDRF_KNM_SOLVE_BLOCKS")) : 256 * 64;
+    if (blocks > kcap) blocks = kcap;
     if (blocks < 1) blocks = 1;
     if constexpr (sizeof(TS) == 8) {
       if (c->kind == 0 && vpr <= 256) {
@@ -1339,6 +1369,13 @@ int gdrf_factorize(gdrf_ctx* c, const void* Z, const void* params, double jitter
   TYPED3(c, factorize, c, (const T*)Z, (const T*)params, jitter, s);
 }
 
+int gdrf_factorize_mode(gdrf_ctx* c, const void* Z, const void* params, double jitter, void* stream, int mode) {
+  HIPCHK(hipSetDevice(c->dev));
+  if (mode < 0 || mode > 2) return fail(-1, "gdrf_factorize_mode", "mode must be 0, 1 or 2");
+  hipStream_t s = (hipStream_t)stream;
+  TYPED3(c, factorize, c, (const T*)Z, (const T*)params, jitter, s, mode);
+}
+
 int gdrf_step_local(gdrf_ctx* c, const void* X, const int32_t* ws, const void* eps, int64_t n, const void* Z, const void* params,
                     void* redT, double* redd, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
@@ -1404,7 +1441,9 @@ int gdrf_chol_failed(gdrf_ctx* c, int* failed, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
   if (int rc = join_fact(c, s)) return rc;
-  HIPCHK(hipMemcpyAsync(failed, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  int two[2] = {0, 0};                       // [0] the factorisation failed, [1] a reused factorisation's inputs had changed
+  HIPCHK(hipMemcpyAsync(two, c->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  *failed = two[0] | two[1];
   return 0;
 }

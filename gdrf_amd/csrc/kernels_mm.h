@@ -23,6 +23,19 @@ __global__ void prep_hyper_kernel(const T* __restrict__ params, Hyper* h) {
   }
 }
 
+// the values a factorisation depends on - the first four parameters (log lengthscale, variance, noise, scale mixture) and the inducing inputs -
+// copied aside (mode 0) or compared bit for bit with that copy (mode 1: *mismatch = 1 if any differs).  One workgroup.
+template <typename T>
+__global__ void fact_snapshot_kernel(const T* __restrict__ params, const T* __restrict__ Z, int64_t nz, T* __restrict__ snap, int mode, int* __restrict__ mismatch) {
+  int bad = 0;
+  for (int64_t e = threadIdx.x; e < nz + 4; e += blockDim.x) {
+    const T v = e < 4 ? params[e] : Z[e - 4];
+    if (mode == 0) snap[e] = v;
+    else if (!(v == snap[e]) && !(v != v && snap[e] != snap[e])) bad = 1;     // equal values (a NaN only matches a NaN)
+  }
+  if (mode == 1 && bad) *mismatch = 1;
+}
+
 // elementwise precision change (inducing points, all-reduced G^T) between the N-side and the solve precision
 template <typename TA, typename TB>
 __global__ void cast_kernel(int64_t n, const TA* __restrict__ in, TB* __restrict__ out) {

@@ -10,6 +10,7 @@ Reference behaviour mirrored here (paths under /root/reference):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional
 
@@ -99,6 +100,7 @@ class Engine:
         self._guess_level: Optional[int] = None      # jitter level of the previous step: this step starts on it speculatively
         self._probe_stream = torch.cuda.Stream(device=self.device)
         self.speculate = True
+        self.prefactorize = os.environ.get("GDRF_PREFACTORIZE", "1") != "0"      # factorise for the next step right behind the optimizer update
         # a caller-supplied link (the reference's `link_function`, abstract_gdrf.py:34-50): a callable on the (K, n) tensor mu returning the
         # (K, n) topic weights; None = the softmax link fused into the row kernel.  Evaluated with torch between three library calls.
         self.link_function = None
@@ -322,8 +324,10 @@ class Engine:
             nlev0 = min(4, self.maxjitter)
             jit0 = (C.c_double * nlev0)(*[self.jitter_total(l) for l in range(nlev0)])
             _lib.check(self.lib.gdrf_probe_launch(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jit0, nlev0, ps), "gdrf_probe_launch")
-            _lib.check(self.lib.gdrf_factorize(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(guess), s),
-                       "gdrf_factorize")
+            # mode 2: a factorisation made ahead of this step (behind the previous optimizer update, see adam()) is reused after a
+            # device-side check that its inputs are still the current ones; gdrf_chol_failed reports a mismatch like a failure
+            _lib.check(self.lib.gdrf_factorize_mode(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(guess), s, 2),
+                       "gdrf_factorize_mode")
             fact_done = torch.cuda.Event()
             fact_done.record(main)
             self._local_and_finish(xs, ws, eps, P, n, ng, llc, s, renyi_alpha)
@@ -468,6 +472,13 @@ class Engine:
         _lib.check(self.lib.gdrf_adam(self.ctx, OPT_MODES[mode], self.params.data_ptr(), self.grads.data_ptr(),
                                       self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.opt_step, lr, betas[0], betas[1],
                                       eps, weight_decay, clip, _stream_ptr(self.device)), "gdrf_adam")
+        # The next step's factorisation depends only on what this update just wrote (kernel hyper-parameters, inducing inputs): start it now,
+        # on the guessed jitter level, so that its serial chain runs while the host reads the loss and enqueues the step.  The step checks
+        # on the device that the inputs are still the same (anything may write the parameters in between) and redoes itself otherwise.
+        if self.speculate and self.prefactorize and self._guess_level is not None:
+            self.refresh_inducing()
+            _lib.check(self.lib.gdrf_factorize_mode(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(self._guess_level),
+                                                    _stream_ptr(self.device), 1), "gdrf_factorize_mode")
 
     def read_out(self) -> Dict[str, float]:
         o = self.out_d.cpu().tolist()          # synchronises

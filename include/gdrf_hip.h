@@ -133,6 +133,12 @@ int gdrf_probe_read(gdrf_ctx* ctx, int nlev, int* failed_host, void* stream);
 /* K_uu + jitter_total*I, its Cholesky factor L and L^{-1} in the solve precision, kept in the context for
  * the calls below. */
 int gdrf_factorize(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream);
+/* The same with a mode: 0 = gdrf_factorize.  1 = factorise AHEAD of the step that will use the result (call it right behind the optimizer
+ * update: the chain then runs while the host reads the loss and enqueues the next step) and keep a copy of its inputs (the kernel
+ * hyper-parameters and Z).  2 = the step's own call: if a mode-1 factorisation with this jitter is waiting, its inputs are only compared
+ * with the current ones on the device - gdrf_chol_failed then reports a mismatch like a failure, and the caller redoes the step with
+ * mode 0; otherwise as mode 0. */
+int gdrf_factorize_mode(gdrf_ctx* ctx, const void* Z_dev, const void* params_dev, double jitter_total, void* stream, int mode);
 
 /* Forward + backward over this rank's n_local observations: everything of one
  * SVI.step(xs, ws) (gdrf/train_script.py:467 -> sparse_gdrf.py:323-409) that is a sum over

@@ -498,3 +498,41 @@ def test_wbar_reduction_slices_for_few_rows(shape):
     assert relerr(GT, Wm.T @ got.double().numpy()) < 2e-5
     eng.loss_and_grads(xs, ws, e, force_level=eng.last_jitter_level)
     assert torch.equal(eng.workspace("Wbar", n).cpu(), got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_factorisation_made_ahead_of_the_step_is_checked_against_its_inputs(dtype):
+    """adam() starts the next step's factorisation (gdrf_factorize_mode 1); the step reuses it after a device-side comparison of the kernel
+    hyper-parameters and inducing inputs it was made from (mode 2).  (a) The trajectory equals the one without this, bit for bit.
+    (b) Writing a hyper-parameter between the update and the next step is noticed: the step redoes itself on the current values."""
+    m, _ = make_oracle(dtype=dtype, jitter=1e-6 if dtype == torch.float64 else 1e-4, W=24, H=12, V=9, K=3, n_points=(6, 5), lr=1e-2)
+    g = torch.Generator().manual_seed(17)
+    eps = [torch.randn(m.K, m.N, generator=g, dtype=torch.float64).to(dtype) for _ in range(4)]
+    runs = {}
+    for ahead in (True, False):
+        eng = engine_from_oracle(m)
+        eng.prefactorize = ahead
+        xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+        losses = []
+        for e in eps:
+            eng.loss_and_grads(xs, ws, dev(e, eng))
+            eng.adam("adam", 1e-2)
+            losses.append(eng.read_out()["loss"])
+        runs[ahead] = (losses, eng.params.clone())
+    assert runs[True][0] == runs[False][0]
+    assert torch.equal(runs[True][1], runs[False][1])
+    # (b)
+    outs = {}
+    for ahead in (True, False):
+        eng = engine_from_oracle(m)
+        eng.prefactorize = ahead
+        xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+        eng.loss_and_grads(xs, ws, dev(eps[0], eng))
+        eng.adam("adam", 1e-2)                                   # (ahead: the factorisation for the next step starts here)
+        eng.read_out()
+        with torch.no_grad():
+            eng.view("log_lengthscale").add_(0.05)               # ... and its input changes behind its back
+        eng.loss_and_grads(xs, ws, dev(eps[1], eng))
+        outs[ahead] = (eng.read_out()["loss"], eng.grads.clone())
+    assert outs[True][0] == outs[False][0]
+    assert torch.equal(outs[True][1], outs[False][1])
