@@ -1195,6 +1195,17 @@ template <typename T, typename TS> struct Impl {
     if ((rc = join_fact(c, s))) return rc;
     ScopedTimer tm(c, 13, s);
     dim3 g2((Mp + 255) / 256, Mp);
+    dim3 g3((M + 255) / 256, M, K);
+    // Sbar_k = 2 A_k S_k and the u_scale_tril gradient do not depend on the Cholesky backward below (a chain of four dependent M x M
+    // products): they run beside it on the side stream (whitened form; the unwhitened one chains them through L^-T further down)
+    const bool sbar_aside = !c->unwhitened;
+    if (sbar_aside) {
+      HIPCHK(hipEventRecord(c->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      if ((rc = mm_nt<T>(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, c->side))) return rc;
+      hipLaunchKernelGGL(grad_s_kernel<T>, g3, dim3(256), 0, c->side, P(c->Sbar), P(c->S), M, Mp, -1.0 / n_global, grads + poff(c, 5));
+      HIPCHK(hipEventRecord(c->ev_join, c->side));
+    }
     // Cholesky / inverse backward in the solve precision
     hipLaunchKernelGGL((cast_kernel<T, TS>), dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, mm, GT, Q(c->GTs));
     // HT = GT Linv ; LbarT = -triu(HT)
@@ -1223,9 +1234,12 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL((grad_z_kernel<TS, T>), dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp,
                          redd + 8, -1.0 / n_global, grads + poff(c, 7));
     // Sbar_k = 2 A_k S_k (N-side precision: well conditioned)
-    if ((rc = mm_nt<T>(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, s))) return rc;
-    dim3 g3((M + 255) / 256, M, K);
-    hipLaunchKernelGGL(grad_s_kernel<T>, g3, dim3(256), 0, s, P(c->Sbar), P(c->S), M, Mp, -1.0 / n_global, grads + poff(c, 5));
+    if (sbar_aside) {
+      HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    } else {
+      if ((rc = mm_nt<T>(c, Ak, mm, P(c->ST), mm, P(c->Sbar), mm, T(2), K, s))) return rc;
+      hipLaunchKernelGGL(grad_s_kernel<T>, g3, dim3(256), 0, s, P(c->Sbar), P(c->S), M, Mp, -1.0 / n_global, grads + poff(c, 5));
+    }
     hipLaunchKernelGGL(grad_small_kernel<T>, dim3(1), dim3(256), 0, s, M, Mp, K, V, c->hyp, redd, c->dsmall, ubar, phib, P(c->phi),
                        c->alpha_dev, c->lgam_const, ll_const, n_global, grads, grads + poff(c, 3), grads + poff(c, 4), c->flag, out_d);
     if (c->unwhitened)       // overwrite the u_loc / u_scale_tril blocks with the gradients chained through L^-T
