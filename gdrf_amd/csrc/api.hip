@@ -888,8 +888,16 @@ template <typename T, typename TS> struct Impl {
     HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     {
       ScopedTimer tm(c, 4, c->side);
-      LocProb<T> p{{}, {}, {}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
-      hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, c->side, p);
+      static const bool loc_rows = !(getenv("GDRF_LOC_ROWS") && getenv("GDRF_LOC_ROWS")[0] == '0');      // A/B knob: 0 = the NT core
+      const size_t ulds = (size_t)K * Mp * sizeof(T);
+      if (loc_rows && K <= LOC_KMAX && Mp % (16 * Vec16<T>::N) == 0 && ulds <= 150 * 1024) {
+        if (ulds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)loc_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ulds));
+        const int64_t blocks = std::min<int64_t>((n + 31) / 32, 256 * 8);
+        hipLaunchKernelGGL(loc_rows_kernel<T>, dim3((unsigned)blocks), dim3(256), ulds, c->side, (const T*)P(c->W), n, Mp, K, (const T*)P(c->Upad), P(c->loc), ldk);
+      } else {
+        LocProb<T> p{{}, {}, {}, P(c->W), n, Mp, K, P(c->Upad), P(c->loc), ldk};
+        hipLaunchKernelGGL((gemm_nt_kernel<T, LocProb<T>>), dim3((unsigned)rtiles), dim3(256), C::LDS_BYTES, c->side, p);
+      }
     }
     HIPCHK(hipEventRecord(c->ev_loc, c->side));
     // W' = (dK_nm / d log lengthscale) Linv^T on the side stream, beside the K-fold contractions (its f64 MFMAs fill their stalls);

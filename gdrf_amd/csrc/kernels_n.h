@@ -405,6 +405,50 @@ __global__ __launch_bounds__(256) void wbar_dot_kernel(const T* __restrict__ Wba
 }
 
 // (1b) loc = W U^T on the matrix cores: Bt = zero-padded u_loc [128][Mp]; stores loc[k][n] for k < K
+// loc = W U^T for a handful of topics as a streaming pass over W (K <= LOC_KMAX): on the NT core the K columns are padded to a 128-wide
+// tile, so 12.8x the useful MFMAs run beside fwd_t (1.1 ms of f32 matrix work there).  Here 16 lanes share a row (16-byte loads, 256 contiguous
+// bytes per step), two row groups per pass reuse every U vector read from LDS, the 16 partial sums meet by xor-shuffles: the 2 GB of W once.
+#define LOC_KMAX 16
+template <typename T>
+__global__ __launch_bounds__(256) void loc_rows_kernel(const T* __restrict__ W, int64_t nrows, int Mp, int K, const T* __restrict__ U /*[>=K][Mp]*/,
+                                                       T* __restrict__ loc, int64_t ldk) {
+  using VT = typename Vec16<T>::type;
+  constexpr int VE = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Us = reinterpret_cast<T*>(smem);                   // [K][Mp]
+  for (int e = threadIdx.x * VE; e < K * Mp; e += blockDim.x * VE) *reinterpret_cast<VT*>(Us + e) = *reinterpret_cast<const VT*>(U + e);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4, wave = threadIdx.x >> 6;
+  const int nsteps = Mp / (16 * VE);                    // Mp is a multiple of 32; the host checks Mp % (16 VE) == 0
+  const int64_t rows_per_pass = 8 * 4;                  // 4 waves x 2 row groups x 4 rows
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_pass + wave * 8; r0 < nrows; r0 += (int64_t)gridDim.x * rows_per_pass) {
+    const int64_t ra = r0 + grp, rb = r0 + 4 + grp;
+    const T* wa = W + (ra < nrows ? ra : 0) * Mp + sub * VE;
+    const T* wb = W + (rb < nrows ? rb : 0) * Mp + sub * VE;
+    T acca[LOC_KMAX], accb[LOC_KMAX];
+#pragma unroll
+    for (int k = 0; k < LOC_KMAX; ++k) { acca[k] = 0; accb[k] = 0; }
+    for (int j = 0; j < nsteps; ++j) {
+      const VT xa = *reinterpret_cast<const VT*>(wa + j * 16 * VE), xb = *reinterpret_cast<const VT*>(wb + j * 16 * VE);
+#pragma unroll
+      for (int k = 0; k < LOC_KMAX; ++k) if (k < K) {
+        const VT u = *reinterpret_cast<const VT*>(Us + k * Mp + j * 16 * VE + sub * VE);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { acca[k] += xa[e] * u[e]; accb[k] += xb[e] * u[e]; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LOC_KMAX; ++k) if (k < K) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { acca[k] += __shfl_xor(acca[k], o, 64); accb[k] += __shfl_xor(accb[k], o, 64); }
+      if (sub == 0) {
+        if (ra < nrows) loc[(int64_t)k * ldk + ra] = acca[k];
+        if (rb < nrows) loc[(int64_t)k * ldk + rb] = accb[k];
+      }
+    }
+  }
+}
+
 template <typename T> struct LocProb : NTDefaultMap, NTPlainA<T>, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr bool SCALE_A = false;
