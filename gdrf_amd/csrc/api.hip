@@ -1025,8 +1025,11 @@ template <typename T, typename TS> struct Impl {
       ScopedTimer tm(c, 12, ss);
       const int64_t rpb = ubar_rows_per_block(n), nb = (n + rpb - 1) / rpb;
       if (nb > c->ubar_blocks_cap) return fail(-1, "gdrf_step_local", "ubar partial buffer too small");
-      hipLaunchKernelGGL(ubar_part_kernel<T>, dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, ss, P(c->W), n, Mp, K, P(c->locbar),
-                         ldk, rpb, P(c->ubar_part));
+      const int kq = K <= 16 ? (K + 3) / 4 : 4;
+#define GDRF_UBAR(Q4) hipLaunchKernelGGL((ubar_part_kernel<T, Q4>), dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, ss, P(c->W), n, Mp, K, P(c->locbar), \
+                                          ldk, rpb, P(c->ubar_part))
+      if (kq == 1) GDRF_UBAR(1); else if (kq == 2) GDRF_UBAR(2); else if (kq == 3) GDRF_UBAR(3); else GDRF_UBAR(4);
+#undef GDRF_UBAR
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, ss, P(c->ubar_part), nb, (int64_t)K * Mp,
                          redT + roff(c, 0));
     }

@@ -1387,7 +1387,8 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
 // [row][16 topics] so that a row's 16 factors are four broadcast 16-byte reads (the one-column form issued 16 LDS reads and one 4-byte
 // load per 16 FMAs and ran at 1 TB/s).  The four waves' sums meet in LDS in a fixed order.
 // =====================================================================================
-template <typename T>
+// KQ: topic quads per pass (K = 10 runs as 3 quads = 12 topics, not 16: the kernel is VALU-bound)
+template <typename T, int KQ = 4>
 __global__ __launch_bounds__(256) void ubar_part_kernel(const T* __restrict__ W, int64_t nrows, int Mp, int K,
                                                         const T* __restrict__ locbar, int64_t ldk, int64_t rows_per_blk,
                                                         T* __restrict__ part /*[gridDim.x][K][Mp]*/) {
@@ -1398,19 +1399,19 @@ __global__ __launch_bounds__(256) void ubar_part_kernel(const T* __restrict__ W,
   const bool cok = col < Mp;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk; if (r1 > nrows) r1 = nrows;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    T4 acc[16];
+  for (int k0 = 0; k0 < K; k0 += 4 * KQ) {
+    T4 acc[4 * KQ];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc[kk] = T4{0, 0, 0, 0};
+    for (int kk = 0; kk < 4 * KQ; ++kk) acc[kk] = T4{0, 0, 0, 0};
     for (int64_t rs = r0; rs < r1; rs += 256) {
       __syncthreads();
       {
         const int64_t n = rs + threadIdx.x;
-        T v[16];
+        T v[4 * KQ];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) v[kk] = (k0 + kk < K && n < r1) ? locbar[(int64_t)(k0 + kk) * ldk + n] : T(0);
+        for (int kk = 0; kk < 4 * KQ; ++kk) v[kk] = (k0 + kk < K && n < r1) ? locbar[(int64_t)(k0 + kk) * ldk + n] : T(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<T4*>(&lb[threadIdx.x][4 * q]) = T4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        for (int q = 0; q < KQ; ++q) *reinterpret_cast<T4*>(&lb[threadIdx.x][4 * q]) = T4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
       }
       __syncthreads();
       const int cnt = (int)((r1 - rs < 256) ? (r1 - rs) : 256);
@@ -1420,7 +1421,7 @@ __global__ __launch_bounds__(256) void ubar_part_kernel(const T* __restrict__ W,
         for (int r = rg; r < cnt; r += 4) {
           const T4 w = *reinterpret_cast<const T4*>(wp + (int64_t)r * Mp);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < KQ; ++q) {
             const T4 l = *reinterpret_cast<const T4*>(&lb[r][4 * q]);
             acc[4 * q] += l[0] * w; acc[4 * q + 1] += l[1] * w; acc[4 * q + 2] += l[2] * w; acc[4 * q + 3] += l[3] * w;
           }
@@ -1430,7 +1431,7 @@ __global__ __launch_bounds__(256) void ubar_part_kernel(const T* __restrict__ W,
     // waves 1..3 hand their sums to wave 0 through LDS (lb is free: 4 topics x 3 waves x 64 lanes x 16 B = 12 KB per pass)
     T4* red = reinterpret_cast<T4*>(&lb[0][0]);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
+    for (int g4 = 0; g4 < KQ; ++g4) {
       __syncthreads();
       if (rg > 0) {
 #pragma unroll
