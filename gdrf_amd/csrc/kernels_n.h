@@ -1461,7 +1461,8 @@ __global__ void reduce_parts_kernel(const T* __restrict__ part, int64_t nparts, 
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= len) return;
   double s = 0;
-  for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * len + e];
+#pragma unroll 16
+  for (int64_t p = 0; p < nparts; ++p) s += (double)part[p * len + e];      // (independent loads in flight; the additions stay in order)
   out[e] = (T)s;
 }
 // out[c] = sum_p part[p][c], c < ncomp ; one block
@@ -1512,7 +1513,10 @@ __global__ void reduce_slabs_kernel(const T* __restrict__ slab, int nsplit, int 
   if (sym && (j / QD) > (i / QD)) return;
   const int64_t mm = (int64_t)Mp * Mp;
   double s = 0;
-  for (int sp = 0; sp < nsplit; ++sp) s += (double)slab[((int64_t)sp * nbatch + b) * mm + (int64_t)i * Mp + j];
+  const T* src = slab + (int64_t)b * mm + (int64_t)i * Mp + j;
+  const int64_t step = (int64_t)nbatch * mm;
+#pragma unroll 8
+  for (int sp = 0; sp < nsplit; ++sp) s += (double)src[(int64_t)sp * step];      // (8 independent loads in flight; the additions stay in order)
   out[(int64_t)b * mm + (int64_t)i * Mp + j] = (T)s;
   if (sym && (j / QD) < (i / QD)) out[(int64_t)b * mm + (int64_t)j * Mp + i] = (T)s;
 }
