@@ -963,7 +963,7 @@ template <typename T, typename TS> struct Impl {
       else hipLaunchKernelGGL((elbo_rows_kernel<T, true, false>), dim3(egrid), dim3(RB), lds, s, GDRF_ROWS_ARGS);
 #undef GDRF_ROWS_ARGS
       LAUNCHCHK("elbo_rows");
-      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
                          (int64_t)K * V, redT + roff(c, 1));
     }
@@ -1039,7 +1039,7 @@ template <typename T, typename TS> struct Impl {
       // on the side stream, behind W' and G^T / ubar: sum Wbar o W -> red_d[4], sum Wbar o W' -> red_d[5]; red_d[6] = 0
       hipStream_t ss = c->side;
       hipLaunchKernelGGL(wbar_dot_kernel<T>, dim3(2048), dim3(256), 0, ss, (const T*)P(c->Wbar), (const T*)P(c->W), (const T*)P(c->Wd), n, Mp, c->wdpart);
-      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, ss, c->wdpart, (int64_t)2048, 2, redd + 4);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, ss, c->wdpart, (int64_t)2048, 2, redd + 4);
       HIPCHK(hipMemsetAsync(redd + 6, 0, sizeof(double), ss));
       HIPCHK(hipEventRecord(c->ev_join, c->side));           // the join event now also covers these
     } else {
@@ -1060,7 +1060,7 @@ template <typename T, typename TS> struct Impl {
         if (sizeof(TS) == 8) hipLaunchKernelGGL((gemm_nt_kernel_v160<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<TS, BwdKnmProb<TS, T>>), dim3((unsigned)nb), dim3(256), CS::LDS_BYTES, s, p);
       }
-      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, nb, 3, redd + 4);      // red_d[4..6]
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, nb, 3, redd + 4);      // red_d[4..6]
     }
     LAUNCHCHK("backward");
     // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
@@ -1141,7 +1141,7 @@ template <typename T, typename TS> struct Impl {
                          c->mean_sn, (const T*)c->mean_g, c->mean_g_sk, c->mean_g_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum),
                          (T*)c->g_vbar, (T*)c->g_locbar, (T*)c->g_asum, P(c->mu), c->dpart, P(c->phibar_part));
       LAUNCHCHK("elbo_rows2");
-      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
                          (int64_t)K * V, redT + roff(c, 1));
     }
@@ -1188,7 +1188,7 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid, (int64_t)K * V,
                          redT + roff(c, 1));
     if (phase == 2) {
-      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+      hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       return step_local(c, X, ws, eps, n, Z, params, redT, redd, s, SL_BACKWARD);
     }
     return 0;
@@ -1240,7 +1240,7 @@ template <typename T, typename TS> struct Impl {
     if ((rc = mm_nt<TS>(c, Q(c->LinvT), 0, Q(c->t0), 0, Q(c->t1), 0, TS(1), 1, s))) return rc;
     hipLaunchKernelGGL(kuu_bar_reduce_kernel<TS>, dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind,
                        c->hyp, c->dpart);
-    hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, (int64_t)M, 3, c->dsmall);
+    hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, (int64_t)M, 3, c->dsmall);
     if (c->learn_z)
       hipLaunchKernelGGL((grad_z_kernel<TS, T>), dim3(M), dim3(256), 0, s, (const TS*)Q(c->t1), (const TS*)Q(c->Zs), M, Mp, c->D, c->kind, c->hyp,
                          redd + 8, -1.0 / n_global, grads + poff(c, 7));
@@ -1291,7 +1291,7 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL((predict_rows_kernel<TS, T>), dim3((unsigned)blocks), dim3(128), lds, s, X, n, (const TS*)Q(c->Zs), M, c->D, c->kind,
                          c->hyp, (const TS*)Q(c->Cf), K, V, (const T*)P(c->phi), ws, mode, out, ldo, c->dpart, in_lds);
     }
-    if (mode == 3) hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->dpart, blocks, 2, out_d);
+    if (mode == 3) hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, blocks, 2, out_d);
     LAUNCHCHK("predict");
     return 0;
   }
@@ -1338,7 +1338,7 @@ int gdrf_ll_const_dev(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_dev
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ll_const_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, n, c->V, c->llpart);
-  hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(256), 0, s, c->llpart, blocks, 1, out_dev);
+  hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->llpart, blocks, 1, out_dev);
   LAUNCHCHK("ll_const");
   return 0;
 }

@@ -1470,7 +1470,8 @@ __global__ void reduce_dparts_kernel(const double* __restrict__ part, int64_t np
   __shared__ double scratch[16];
   for (int c = 0; c < ncomp; ++c) {
     double s = 0;
-    for (int64_t p = threadIdx.x; p < nparts; p += blockDim.x) s += part[p * ncomp + c];
+#pragma unroll 8
+    for (int64_t p = threadIdx.x; p < nparts; p += blockDim.x) s += part[p * ncomp + c];      // 1024 threads, independent loads in flight
     s = block_sum(s, scratch);
     if (threadIdx.x == 0) out[c] = s;
   }
