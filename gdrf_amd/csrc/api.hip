@@ -979,6 +979,27 @@ template <typename T, typename TS> struct Impl {
         split_scales(c, SPLIT_SC_V, s);
       }
     }
+    // ubar = locbar W needs only the row kernel's locbar: on the side stream BESIDE the Wbar contraction (a vector / HBM pass next to a
+    // matrix-pipe kernel that leaves half of each SIMD's registers free) instead of inside bwd_knm with G^T (GDRF_UBAR_EARLY=0: there)
+    static const bool ubar_early = !(getenv("GDRF_UBAR_EARLY") && getenv("GDRF_UBAR_EARLY")[0] == '0');
+    auto launch_ubar = [&](hipStream_t ss) -> int {
+      ScopedTimer tm(c, 12, ss);
+      const int64_t rpb = ubar_rows_per_block(n), nb = (n + rpb - 1) / rpb;
+      if (nb > c->ubar_blocks_cap) return fail(-1, "gdrf_step_local", "ubar partial buffer too small");
+      const int kq = K <= 16 ? (K + 3) / 4 : 4;
+#define GDRF_UBAR(Q4) hipLaunchKernelGGL((ubar_part_kernel<T, Q4>), dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, ss, P(c->W), n, Mp, K, P(c->locbar), \
+                                          ldk, rpb, P(c->ubar_part))
+      if (kq == 1) GDRF_UBAR(1); else if (kq == 2) GDRF_UBAR(2); else if (kq == 3) GDRF_UBAR(3); else GDRF_UBAR(4);
+#undef GDRF_UBAR
+      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, ss, P(c->ubar_part), nb, (int64_t)K * Mp,
+                         redT + roff(c, 0));
+      return 0;
+    };
+    if (ubar_early) {
+      HIPCHK(hipEventRecord(c->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      if ((rc = launch_ubar(c->side))) return rc;
+    }
     // (3) Wbar
     {
       ScopedTimer tm(c, 7, s);
@@ -1022,16 +1043,7 @@ template <typename T, typename TS> struct Impl {
       { ScopedTimer tm(c, 11, ss);
         dim3 gr1((Mp + 255) / 256, Mp, 1);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr1, dim3(256), 0, ss, (const T*)slab_gt, ns, 1, Mp, 0, redT + roff(c, 3)); }
-      ScopedTimer tm(c, 12, ss);
-      const int64_t rpb = ubar_rows_per_block(n), nb = (n + rpb - 1) / rpb;
-      if (nb > c->ubar_blocks_cap) return fail(-1, "gdrf_step_local", "ubar partial buffer too small");
-      const int kq = K <= 16 ? (K + 3) / 4 : 4;
-#define GDRF_UBAR(Q4) hipLaunchKernelGGL((ubar_part_kernel<T, Q4>), dim3((unsigned)nb, (Mp + 255) / 256), dim3(256), 0, ss, P(c->W), n, Mp, K, P(c->locbar), \
-                                          ldk, rpb, P(c->ubar_part))
-      if (kq == 1) GDRF_UBAR(1); else if (kq == 2) GDRF_UBAR(2); else if (kq == 3) GDRF_UBAR(3); else GDRF_UBAR(4);
-#undef GDRF_UBAR
-      hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * Mp + 255) / 256), dim3(256), 0, ss, P(c->ubar_part), nb, (int64_t)K * Mp,
-                         redT + roff(c, 0));
+      if (!ubar_early && (rc = launch_ubar(ss))) return rc;
     }
     HIPCHK(hipEventRecord(c->ev_join, c->side));
     // (4) kernel hyper-parameter partials through K_nm
