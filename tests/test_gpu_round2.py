@@ -521,18 +521,23 @@ def test_factorisation_made_ahead_of_the_step_is_checked_against_its_inputs(dtyp
         runs[ahead] = (losses, eng.params.clone())
     assert runs[True][0] == runs[False][0]
     assert torch.equal(runs[True][1], runs[False][1])
-    # (b)
-    outs = {}
-    for ahead in (True, False):
-        eng = engine_from_oracle(m)
-        eng.prefactorize = ahead
-        xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
-        eng.loss_and_grads(xs, ws, dev(eps[0], eng))
-        eng.adam("adam", 1e-2)                                   # (ahead: the factorisation for the next step starts here)
-        eng.read_out()
-        with torch.no_grad():
-            eng.view("log_lengthscale").add_(0.05)               # ... and its input changes behind its back
-        eng.loss_and_grads(xs, ws, dev(eps[1], eng))
-        outs[ahead] = (eng.read_out()["loss"], eng.grads.clone())
-    assert outs[True][0] == outs[False][0]
-    assert torch.equal(outs[True][1], outs[False][1])
+    # (b): a hyper-parameter (input of the factorisation) or a variational parameter (input of the transforms made ahead with it)
+    for name, delta in (("log_lengthscale", 0.05), ("u_loc", 0.01), ("u_scale_tril_unc", 0.01), ("log_variance", 0.03)):
+        outs = {}
+        for ahead in (True, False):
+            eng = engine_from_oracle(m)
+            eng.prefactorize = ahead
+            xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
+            eng.loss_and_grads(xs, ws, dev(eps[0], eng))
+            eng.adam("adam", 1e-2)                               # (ahead: the work for the next step starts here)
+            eng.read_out()
+            with torch.no_grad():
+                eng.view(name).add_(delta)                       # ... and its input changes behind its back
+            eng.loss_and_grads(xs, ws, dev(eps[1], eng))
+            first = (eng.read_out()["loss"], eng.grads.clone())
+            eng.adam("adam", 1e-2)
+            eng.loss_and_grads(xs, ws, dev(eps[2], eng))         # and the step after the redone one is an ordinary one again
+            outs[ahead] = first + (eng.read_out()["loss"],)
+        assert outs[True][0] == outs[False][0], name
+        assert torch.equal(outs[True][1], outs[False][1]), name
+        assert outs[True][2] == outs[False][2], name
