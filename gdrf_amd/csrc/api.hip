@@ -7,6 +7,7 @@
 #include "gemm_tn_topics.h"
 #include "kernels_mm.h"
 #include "kernels_n.h"
+#include "predict.h"
 
 #include <algorithm>
 #include <cmath>
@@ -49,7 +50,7 @@ struct gdrf_ctx {
   int nsplit_cap;
   // solve precision, M x M (ld Mp)
   void *mmslab; size_t mmslab_bytes;    // split-K slabs of the small M x M products: [slices][batch][Mp][Mp]
-  void *Kuu, *Lw, *Lo, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *Zs, *GTs;      // Lo: the panel-wise factorisation's output (Lw is its work matrix)
+  void *Kuu, *Lw, *Lo, *L, *LT, *Linv, *LinvT, *Dinv, *t0, *t1, *t2, *Cf, *CfT, *Zs, *GTs;      // Lo: the panel-wise factorisation's output (Lw is its work matrix)
   void *Knm;                  // [ncap][Mp] K_nm in the solve precision (forward A operand, backward epilogue)
   // probe (N-side precision) scratch, only when T != TS
   void *pK, *pL;
@@ -71,7 +72,8 @@ struct gdrf_ctx {
   double *llpart;             // per-workgroup partials of the data constant (own buffer: it may be queued beside a step)
   int64_t dpart_len, ubar_blocks_cap, erows_grid_cap;
   double* alpha_dev; double lgam_const;
-  Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[1]: a reused factorisation's inputs changed; flag[8..16): probe levels failed
+  Hyper *hyp, *hyp_probe; int* flag;        // flag[0]: solve factorisation failed; flag[8..16): probe levels failed; flag[16]: a reused factorisation's inputs changed (own
+                                            // 64-byte line, written only by the compare kernel and by reuse_clear below: the side stream's memset of flag[0..8) never touches it)
   void* snap; int prefact_valid; double prefact_jitter;     // the inputs of a factorisation made ahead of its step (gdrf_factorize_mode)
   hipStream_t side;           // small, tail-heavy kernels run here beside the big GEMMs (fork/join with events)
   hipEvent_t ev_fork, ev_loc, ev_fork2, ev_join, ev_fact0, ev_fact;
@@ -244,7 +246,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->mmslab, c->mmslab_bytes) AL(c->L, mms) AL(c->LT, mms) AL(c->Linv, mms) AL(c->LinvT, mms)
   AL(c->Dinv, (size_t)(c->Mp / 32) * 1024 * c->ssz)
   AL(c->t0, mms) AL(c->t1, mms) AL(c->t2, mms) AL(c->GTs, mms)
-  AL(c->Cf, (size_t)K * M * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
+  AL(c->Cf, (size_t)K * M * c->ssz) AL(c->CfT, (size_t)c->Mp * 32 * c->ssz) AL(c->Zs, (size_t)c->Mp * D * c->ssz)
   AL(c->Knm, (size_t)n_cap * c->Mp * c->ssz)
   AL(c->pK, mm) AL(c->pL, mm * 8)          // probe scratch: K_uu without jitter, 8 level copies
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
@@ -278,7 +280,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->dsmall, 16 * sizeof(double))
   AL(c->llpart, 2048 * sizeof(double))
   AL(c->alpha_dev, (size_t)K * V * sizeof(double))
-  AL(c->hyp, sizeof(Hyper)) AL(c->hyp_probe, sizeof(Hyper)) AL(c->flag, 64)
+  AL(c->hyp, sizeof(Hyper)) AL(c->hyp_probe, sizeof(Hyper)) AL(c->flag, 128)
   AL(c->ssc, (size_t)SplitLay{K}.nfloats() * sizeof(float)) AL(c->smx, (size_t)SplitLay{K}.nmax() * sizeof(unsigned))
 #undef AL
   {
@@ -294,7 +296,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   }
   for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact, &c->ev_wd})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  HIPCHK(hipMemset(c->flag, 0, 64));
+  HIPCHK(hipMemset(c->flag, 0, 128));
   HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
   std::vector<double> a((size_t)K * V, 1.0);
   *out = c;
@@ -515,18 +517,20 @@ template <typename T, typename TS> struct Impl {
   // solve-precision K_nm of gdrf_step_local) overlaps it.  Every consumer of L calls join_fact() first.
   // mode 0: factorise.  mode 1: factorise AHEAD of the step that will use it (right behind the optimizer update, so that the chain runs while
   // the host reads the loss and enqueues the next step) and keep a copy of its inputs.  mode 2: the step's own call - if a mode-1
-  // factorisation with this jitter is waiting, only compare its inputs with the current ones on the device (flag[1], read with the
+  // factorisation with this jitter is waiting, only compare its inputs with the current ones on the device (flag[16], read with the
   // failure flag by gdrf_chol_failed: a mismatch makes the caller redo the step, like a wrong jitter guess); otherwise as mode 0.
   static int factorize(gdrf_ctx* c, const T* Z, const T* params, double jitter, hipStream_t s, int mode = 0) {
     const int Mp = c->Mp, M = c->M;
     const int64_t nzs = (int64_t)M * c->D;
     if (mode == 2 && c->prefact_valid && jitter == c->prefact_jitter) {
-      hipLaunchKernelGGL(fact_snapshot_kernel<T>, dim3(1), dim3(256), 0, s, params, Z, nzs, P(c->snap), 1, c->flag + 1);
-      c->prefact_valid = 0;
+      hipLaunchKernelGGL(fact_snapshot_kernel<T>, dim3(1), dim3(256), 0, s, params, Z, nzs, P(c->snap), 1, c->flag + 16);
+      // the factorisation stays valid for further calls with the same inputs (a predictive evaluation between two steps): every reuse
+      // compares again, and any fresh factorisation below invalidates it first
       LAUNCHCHK("factorize (reuse)");
       return 0;
     }
     c->prefact_valid = 0;
+    if (mode != 1) HIPCHK(hipMemsetAsync(c->flag + 16, 0, sizeof(int), s));     // this stream's own factorisation: nothing reused, no mismatch to report
     dim3 g2((Mp + 255) / 256, Mp);
     hipLaunchKernelGGL(prep_hyper_kernel<T>, dim3(1), dim3(64), 0, s, params, c->hyp);
     const int64_t nz = (int64_t)M * c->D;
@@ -1282,7 +1286,39 @@ template <typename T, typename TS> struct Impl {
                          (T*)c->Uw);
       U = (const T*)c->Uw;
     }
+    if (mode == 4) {
+      // (f_loc, f_var) of gp.util.conditional(full_cov=False) (gdrf/models/sparse_gdrf.py:277-319): the step's own forward - transforms,
+      // K_nm, W = K_nm L^-T with its row norms, loc = W U^T, tt = |S_k^T w|^2 - and one pass that assembles the variance
+      if (n > c->ncap) return fail(-1, "gdrf_predict", "mode 4 (loc, var) needs n <= n_cap");
+      if (int rc = step_local(c, X, nullptr, nullptr, n, Z, params, nullptr, nullptr, s, SL_TRANSFORMS | SL_FORWARD)) return rc;
+      hipLaunchKernelGGL(predict_var_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, K, c->hyp, (const T*)P(c->qpart), nct<TS>(c),
+                         (const T*)P(c->loc), (const T*)P(c->tt), c->ldk, out);
+      LAUNCHCHK("predict (loc, var)");
+      return 0;
+    }
     if (mode >= 2) hipLaunchKernelGGL(build_phi_kernel<T>, dim3(K), dim3(64), 0, s, params + poff(c, 4), K, V, P(c->phi));
+    {
+      // matrix-core form (predict.h): a wave owns 16 rows, one covariance value per lane and step is the A operand of the 16x16x4
+      // matrix instruction, the padded transposed coefficients CfT its B operand.  K <= 32, the scaled inducing inputs in LDS.
+      static const bool mfma_on = !(getenv("GDRF_PREDICT_MFMA") && getenv("GDRF_PREDICT_MFMA")[0] == '0');     // A/B knob: 0 = one thread per row
+      const int M4 = (int)round_up(M, 4), NB = K <= 16 ? 1 : 2, DDt = c->D <= 2 ? 2 : GDRF_DMAX;
+      const size_t lds = 128 + ((size_t)M4 * DDt + (size_t)K * V + (size_t)4 * 16 * (16 * NB + 1)) * sizeof(TS);
+      if (mfma_on && K <= 32 && lds <= 64 * 1024) {
+        const int ldc = 16 * NB;
+        hipLaunchKernelGGL((predict_coeff_t_kernel<TS, T>), dim3((M4 + 127) / 128, ldc), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, M4, K, ldc, Q(c->CfT));
+        const int64_t groups = (n + 15) / 16;
+        int64_t blocks = (groups + 3) / 4; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+        const int64_t ldo = mode == 0 ? n : (mode == 1 ? K : V);
+#define GDRF_PM(DDv, NBv) { if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)predict_mfma_kernel<TS, T, DDv, NBv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                            hipLaunchKernelGGL((predict_mfma_kernel<TS, T, DDv, NBv>), dim3((unsigned)blocks), dim3(256), lds, s, X, n, (const TS*)Q(c->Zs), M, M4, c->D, c->kind, \
+                                               c->hyp, (const TS*)Q(c->CfT), K, V, (const T*)P(c->phi), ws, mode, out, ldo, c->dpart); }
+        if (DDt == 2) { if (NB == 1) GDRF_PM(2, 1) else GDRF_PM(2, 2) } else { if (NB == 1) GDRF_PM(GDRF_DMAX, 1) else GDRF_PM(GDRF_DMAX, 2) }
+#undef GDRF_PM
+        if (mode == 3) hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, blocks, 2, out_d);
+        LAUNCHCHK("predict (mfma)");
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((predict_coeff_kernel<TS, T>), dim3((M + 127) / 128, K), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, K, Q(c->Cf));
     int64_t blocks = (n + 127) / 128; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     const int64_t ldo = mode == 0 ? n : (mode == 1 ? K : V);
@@ -1468,7 +1504,8 @@ int gdrf_adam(gdrf_ctx* c, int mode, void* params, const void* grads, void* m, v
 int gdrf_predict(gdrf_ctx* c, const void* X, int64_t n, const void* Z, const void* params, const int32_t* ws, int mode,
                  void* out, double* out_d, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
-  if (mode < 0 || mode > 3) return fail(-1, "gdrf_predict", "mode");
+  if (mode < 0 || mode > 4) return fail(-1, "gdrf_predict", "mode");
+  if (n < 1) return fail(-1, "gdrf_predict", "n must be >= 1");
   if (mode == 3 && !ws) return fail(-1, "gdrf_predict", "perplexity needs ws");
   hipStream_t s = (hipStream_t)stream;
   TYPED3(c, predict, c, (const T*)X, n, (const T*)Z, (const T*)params, ws, mode, (T*)out, out_d, s);
@@ -1478,9 +1515,9 @@ int gdrf_chol_failed(gdrf_ctx* c, int* failed, void* stream) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t s = (hipStream_t)stream;
   if (int rc = join_fact(c, s)) return rc;
-  int two[2] = {0, 0};                       // [0] the factorisation failed, [1] a reused factorisation's inputs had changed
-  HIPCHK(hipMemcpyAsync(two, c->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  int f17[17];                               // [0] the factorisation failed, [16] a reused factorisation's inputs had changed
+  HIPCHK(hipMemcpyAsync(f17, c->flag, sizeof(f17), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  *failed = two[0] | two[1];
+  *failed = f17[0] | f17[16];
   return 0;
 }

@@ -24,9 +24,15 @@ __global__ void prep_hyper_kernel(const T* __restrict__ params, Hyper* h) {
 }
 
 // the values a factorisation depends on - the first four parameters (log lengthscale, variance, noise, scale mixture) and the inducing inputs -
-// copied aside (mode 0) or compared bit for bit with that copy (mode 1: *mismatch = 1 if any differs).  One workgroup.
+// copied aside (mode 0) or compared bit for bit with that copy (mode 1: *mismatch = 1 if any differs, 0 otherwise - written
+// unconditionally, so the word needs no clearing by anyone else: a memset queued on another stream could land after this kernel and
+// erase a mismatch).  One workgroup.
 template <typename T>
 __global__ void fact_snapshot_kernel(const T* __restrict__ params, const T* __restrict__ Z, int64_t nz, T* __restrict__ snap, int mode, int* __restrict__ mismatch) {
+  if (mode == 1) {
+    if (threadIdx.x == 0) *mismatch = 0;
+    __syncthreads();
+  }
   int bad = 0;
   for (int64_t e = threadIdx.x; e < nz + 4; e += blockDim.x) {
     const T v = e < 4 ? params[e] : Z[e - 4];

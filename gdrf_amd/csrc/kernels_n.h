@@ -1065,25 +1065,40 @@ __global__ __launch_bounds__(128) void elbo_rows_kernel(
       }
       s_llw += (double)llw;
       // thetabar_k = sum_v phi_kv pbar_v ; softmax Jacobian
+      // softmax pull-back mubar_k = theta_k (thetabar_k - sum_j theta_j thetabar_j).  mu = loc + v eps has a spread of tens of units (the
+      // reference passes the predictive VARIANCE as the Normal's scale, quirk Q1), so one theta is 1 - O(1e-4) and the literal form
+      // subtracts two numbers of size thetabar ~ sum_v w_v that agree to 4 digits: 1e-3 relative error in float.  With ANY constant c,
+      // thetabar_k - dot = (thetabar_k - c) + sum_j theta_j (c - thetabar_j)   (sum_j theta_j = 1);  c = thetabar of the dominant topic
+      // removes the large term from the sum - every product then carries a small theta_j or is exactly zero.
       T tb[KR];
-      T dot = 0;
+      T cref = 0;
       if constexpr (KREG) {
 #pragma unroll
         for (int k = 0; k < KR; ++k) if (k < K) {
           T s = 0;
           for (int vv = 0; vv < V; ++vv) s += phiS[k * V + vv] * pb[vv];
-          tb[k] = s; dot += th[k] * s;
+          tb[k] = s;
+          if (mu[k] == mx) cref = s;
         }
       } else {
+        T tmax = -1;
         for (int k = 0; k < K; ++k) {
           T s = 0;
           for (int vv = 0; vv < V; ++vv) s += phiS[k * V + vv] * pb[vv];
-          tbl[k] = s; dot += th[k] * s;
+          tbl[k] = s;
+          if (th[k] > tmax) { tmax = th[k]; cref = s; }
         }
+      }
+      T dot = 0;                                     // = sum_j theta_j (cref - thetabar_j)
+      if constexpr (KREG) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) if (k < K) dot += th[k] * (cref - tb[k]);
+      } else {
+        for (int k = 0; k < K; ++k) dot += th[k] * (cref - tbl[k]);
       }
       T site = 0, ng = 0, vsum = 0;
       auto finish_topic = [&](int k, T vk, T ek, T mk, T tbk) {
-        const T mub = th[k] * (tbk - dot);
+        const T mub = th[k] * ((tbk - cref) + dot);
         const T s = vk + eta, r = vk / s, e2 = ek * ek;
         site += -t_log<T>(s) + t_log<T>(vk) - T(0.5) * e2 * r * r + T(0.5) * e2;
         const T dcdv = -T(1) / s + T(1) / vk - e2 * r * eta / (s * s);
@@ -1320,8 +1335,16 @@ __global__ __launch_bounds__(64) void elbo_rows2_kernel(
         pb[vv] = inr ? wv / p : T(0);
       }
       s_llw += (double)llw;
-      T dot = 0;
-      for (int k = 0; k < K; ++k) { T sum = 0; for (int vv = 0; vv < V; ++vv) sum += phiS[k * V + vv] * pb[vv]; tb[k] = sum; dot += th[k] * sum; }
+      // cancellation-free softmax pull-back, as in elbo_rows_kernel: reference value = thetabar of the dominant topic
+      T cref = 0, tmax = -1;
+      for (int k = 0; k < K; ++k) {
+        T sum = 0;
+        for (int vv = 0; vv < V; ++vv) sum += phiS[k * V + vv] * pb[vv];
+        tb[k] = sum;
+        if (th[k] > tmax) { tmax = th[k]; cref = sum; }
+      }
+      T dot = 0;                                     // = sum_j theta_j (cref - thetabar_j)
+      for (int k = 0; k < K; ++k) dot += th[k] * (cref - tb[k]);
       T site = 0, ng = 0, vsm = 0, vsg = 0;
       for (int k = 0; k < K; ++k) {
         T vg, ek;
@@ -1329,7 +1352,7 @@ __global__ __launch_bounds__(64) void elbo_rows2_kernel(
         const T vm = v0m + tt_m[(int64_t)k * ldk + n], sm = vm + eta;
         T lm = loc_m[(int64_t)k * ldk + n];
         if (mean_m) lm += mean_m[(int64_t)k * mm_sk + n * mm_sn];
-        const T d = mu - lm, mub = th[k] * (tb[k] - dot);
+        const T d = mu - lm, mub = th[k] * ((tb[k] - cref) + dot);
         site += -t_log<T>(sm) - T(0.5) * (d / sm) * (d / sm) + t_log<T>(vg) + T(0.5) * ek * ek;
         const T lbm = d / (sm * sm), vbm = -T(1) / sm + d * d / (sm * sm * sm);
         const T lbg = mub - lbm, vbg = lbg * ek + T(1) / vg;

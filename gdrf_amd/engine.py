@@ -485,21 +485,58 @@ class Engine:
         return dict(loss=o[0], chol_failed=o[1], site=o[2], loglik=o[3], lp_phi=o[4])
 
     def predict(self, xs: torch.Tensor, mode: int, ws: Optional[torch.Tensor] = None):
+        """Predictive path (gdrf_predict): mode 0 f_loc (K, n), 1 topic_probs (n, K), 2 word_probs (n, V), 3 {sum w log p, sum w},
+        4 (f_loc, f_var) as (2, K, n).  Like the step, it starts on the previous jitter level (and on the factorisation adam() queued
+        ahead, if its inputs still match) while the array-precision probe that decides the level runs on the second stream; a wrong
+        guess redoes the evaluation on the right level."""
         self._chk_rows(xs, ws)
         n = xs.shape[0]
         self.refresh_inducing()
-        self.factorize()
-        out = None
-        if mode == 0:
-            out = torch.empty(self.K, n, dtype=self.dtype, device=self.device)
-        elif mode == 1:
-            out = torch.empty(n, self.K, dtype=self.dtype, device=self.device)
-        elif mode == 2:
-            out = torch.empty(n, self.V, dtype=self.dtype, device=self.device)
-        _lib.check(self.lib.gdrf_predict(self.ctx, xs.data_ptr(), n, self.Z.data_ptr(), self.params.data_ptr(),
-                                         ws.data_ptr() if ws is not None else None, mode,
-                                         out.data_ptr() if out is not None else None, self.out_d.data_ptr(),
-                                         _stream_ptr(self.device)), "gdrf_predict")
-        if mode == 3:
-            return self.out_d[:2].clone()
-        return out
+        if mode == 4 and n > self.n_cap:
+            raise ValueError(f"predict(mode=4) needs n <= n_cap ({n} > {self.n_cap})")
+
+        def run():
+            out = None
+            if mode == 0:
+                out = torch.empty(self.K, n, dtype=self.dtype, device=self.device)
+            elif mode == 1:
+                out = torch.empty(n, self.K, dtype=self.dtype, device=self.device)
+            elif mode == 2:
+                out = torch.empty(n, self.V, dtype=self.dtype, device=self.device)
+            elif mode == 4:          # (f_loc, f_var) of gp.util.conditional(full_cov=False): sparse_gdrf.py:277-319
+                out = torch.empty(2, self.K, n, dtype=self.dtype, device=self.device)
+            _lib.check(self.lib.gdrf_predict(self.ctx, xs.data_ptr(), n, self.Z.data_ptr(), self.params.data_ptr(),
+                                             ws.data_ptr() if ws is not None else None, mode,
+                                             out.data_ptr() if out is not None else None, self.out_d.data_ptr(),
+                                             _stream_ptr(self.device)), "gdrf_predict")
+            return self.out_d[:2].clone() if mode == 3 else out
+
+        guess = self._guess_level if self.speculate else None
+        if guess is None:
+            self.factorize()
+            return run()
+        main = torch.cuda.current_stream(self.device)
+        self._probe_stream.wait_stream(main)
+        ps = self._probe_stream.cuda_stream
+        nlev0 = min(4, self.maxjitter)
+        jit0 = (C.c_double * nlev0)(*[self.jitter_total(l) for l in range(nlev0)])
+        _lib.check(self.lib.gdrf_probe_launch(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), jit0, nlev0, ps), "gdrf_probe_launch")
+        _lib.check(self.lib.gdrf_factorize_mode(self.ctx, self.Z.data_ptr(), self.params.data_ptr(), self.jitter_total(guess),
+                                                main.cuda_stream, 2), "gdrf_factorize_mode")
+        fact_done = torch.cuda.Event()
+        fact_done.record(main)
+        out = run()
+        flags0 = (C.c_int * nlev0)()
+        _lib.check(self.lib.gdrf_probe_read(self.ctx, nlev0, flags0, ps), "gdrf_probe_read")
+        ok0 = [l for l in range(nlev0) if not flags0[l]]
+        level = ok0[0] if ok0 else self._probe_level(ps, start=nlev0)
+        failed = C.c_int()
+        self._probe_stream.wait_event(fact_done)
+        _lib.check(self.lib.gdrf_chol_failed(self.ctx, C.byref(failed), ps), "gdrf_chol_failed")
+        if level == guess and not failed.value:
+            self.last_jitter_level = level
+            return out
+        torch.cuda.synchronize(self.device)
+        self.factorize(None)
+        self._guess_level = self.last_jitter_level
+        return run()

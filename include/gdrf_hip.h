@@ -31,7 +31,7 @@ typedef struct gdrf_ctx gdrf_ctx;
 enum { GDRF_F32 = 0, GDRF_F64 = 1, GDRF_F32_PURE = 2 };
 enum { GDRF_RBF = 0, GDRF_MATERN52 = 1, GDRF_MATERN32 = 2, GDRF_EXPONENTIAL = 3, GDRF_RATIONALQUADRATIC = 4 };
 enum { GDRF_ADAM = 0, GDRF_ADAMW = 1, GDRF_CLIPPED_ADAM = 2 };
-enum { GDRF_PRED_LOC = 0, GDRF_PRED_TOPIC_PROBS = 1, GDRF_PRED_WORD_PROBS = 2, GDRF_PRED_PERPLEXITY = 3 };
+enum { GDRF_PRED_LOC = 0, GDRF_PRED_TOPIC_PROBS = 1, GDRF_PRED_WORD_PROBS = 2, GDRF_PRED_PERPLEXITY = 3, GDRF_PRED_LOC_VAR = 4 };
 
 const char* gdrf_last_error(void);
 int gdrf_version(void);
@@ -181,7 +181,12 @@ int gdrf_adam(gdrf_ctx* ctx, int mode, void* params_dev, const void* grads_dev, 
 
 /* Predictive mean path: log_topic_probs / topic_probs / word_probs / perplexity
  * (gdrf/models/sparse_gdrf.py:161-186, abstract_gdrf.py:113-139).  mode 0: out (K,n) ;
- * 1: out (n,K) ; 2: out (n,V) ; 3: out_d_dev[0..1] = {sum w log p, sum w}.  Needs gdrf_factorize(). */
+ * 1: out (n,K) ; 2: out (n,V) ; 3: out_d_dev[0..1] = {sum w log p, sum w}.  Modes 0-3 never form the variance (the reference
+ * computes and discards it, quirk Q4): K_nm is generated tile by tile as the A operand of the solve-precision matrix instruction and
+ * multiplied with L^-T u (csrc/predict.h); any n.
+ * mode 4: out (2,K,n) = {f_loc, f_var} of gp.util.conditional(full_cov=False) as SparseGDRF.forward(Xnew) returns them
+ * (gdrf/models/sparse_gdrf.py:277-319; the mean_function is added by the caller): the step's forward (K_nm, W = K_nm L^-T,
+ * loc = W U^T, tt = |S_k^T w|^2) plus one pass for var = clamp(variance - |w|^2, 0) + tt; n <= n_cap.  Needs gdrf_factorize(). */
 int gdrf_predict(gdrf_ctx* ctx, const void* X_dev, int64_t n, const void* Z_dev, const void* params_dev,
                  const int32_t* ws_dev, int mode, void* out_dev, double* out_d_dev, void* stream);
 

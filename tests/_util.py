@@ -10,7 +10,7 @@ NAME_MAP = dict(log_lengthscale="log_lengthscale", log_variance="log_variance", 
 
 def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.float64, seed=1, jitter=1e-6,
                 perturb=True, one_d=False, optimizer="adam", lr=1e-3, force_jitter_level=None, lengthscale=0.1,
-                learn_inducing=False, random_inducing=False, scale_mixture=1.0, whiten=True, mean_function=None):
+                learn_inducing=False, random_inducing=False, scale_mixture=1.0, whiten=True, mean_function=None, s_perturb=0.1, trained_scale=None):
     xs, ws, _ = synth_circles(W, H, V, K, seed=seed, one_d=one_d)
     g = torch.Generator().manual_seed(seed + 100)
     Z = None
@@ -23,8 +23,15 @@ def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.f
     if perturb:
         with torch.no_grad():
             m.params["u_loc"].add_(0.3 * torch.randn(m.params["u_loc"].shape, generator=g, dtype=torch.float64).to(dtype))
-            m.params["u_scale_tril_unc"].add_(
-                0.1 * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril().to(dtype))
+            if trained_scale is not None:
+                # a posterior that has contracted, as after training: S_k = trained_scale I + small lower-triangular noise (the
+                # initial S_k = L_uu of sparse_gdrf.py:100-110 makes tt = |S^T w|^2 - hence mu = loc + v eps - as large as cond(K_uu))
+                u = s_perturb * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril(-1)
+                u = u + torch.diag_embed(torch.full(m.params["u_loc"].shape, float(np.log(trained_scale)), dtype=torch.float64))
+                m.params["u_scale_tril_unc"].copy_(u.to(dtype))
+            else:
+                m.params["u_scale_tril_unc"].add_(
+                    s_perturb * torch.randn(m.params["u_scale_tril_unc"].shape, generator=g, dtype=torch.float64).tril().to(dtype))
             m.params["phi_unc"].add_(0.5 * torch.randn(m.params["phi_unc"].shape, generator=g, dtype=torch.float64).to(dtype))
             m.params["log_noise"].add_(0.2)
     eps = torch.randn(K, m.N, generator=g, dtype=torch.float64).to(dtype)

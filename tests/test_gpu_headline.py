@@ -80,6 +80,7 @@ def test_full_size_step_against_the_chunked_fp64_oracle_and_row_split_linearity(
     with torch.no_grad():
         for name in eng.PARAM_NAMES:
             ref.params[name].copy_(eng.view(name).cpu().double())
+        ref.Z = eng.Z.cpu().double()          # the float32-rounded inducing grid the engine (and the all-float32 reference) holds
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
     t0 = time.time()
     loss_ref, grads_ref = ref.loss_chunked(eps.cpu().double(), torch.from_numpy(headline["xs_np"]).double(),

@@ -29,7 +29,8 @@ def _run(dtype, W, H, steps):
                          lr=1e-3, lengthscale=0.1, force_jitter_level=lvl)
     for k in m64.params:
         with torch.no_grad():
-            m64.params[k].copy_(eng.view(k).detach().cpu().double() if False else m32.params[k].detach().double())
+            m64.params[k].copy_(m32.params[k].detach().double())
+    m64.Z = m32.Z.double()                  # the float32-rounded inducing grid, as the engine holds it
     for name in eng.PARAM_NAMES:
         eng.view(name).copy_(m64.params[name].detach().to(eng.dtype))
     g = torch.Generator().manual_seed(3)

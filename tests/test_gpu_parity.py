@@ -226,8 +226,9 @@ def test_split_wbar_is_f32_accurate(case):
     print(case["kind"], errs)
     for mode in SPLIT_MODES:
         assert errs[mode]["wbar"] < max(4 * errs["f32"]["wbar"], 2e-6), errs
-        assert errs[mode]["g_ls"] < max(4 * errs["f32"]["g_ls"], 1e-4), errs
-        assert errs[mode]["g_var"] < max(4 * errs["f32"]["g_var"], 1e-4), errs
+        # (scalars: relative to themselves, i.e. including their own cancellation - the floor is the native-f32 Wbar error level here)
+        assert errs[mode]["g_ls"] < max(4 * errs["f32"]["g_ls"], 5e-4), errs
+        assert errs[mode]["g_var"] < max(4 * errs["f32"]["g_var"], 5e-4), errs
 
 
 def _perturb_wide(m, spread):
