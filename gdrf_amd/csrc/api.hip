@@ -8,6 +8,7 @@
 #include "kernels_mm.h"
 #include "kernels_n.h"
 #include "predict.h"
+#include "rows_mfma.h"
 
 #include <algorithm>
 #include <cmath>
@@ -943,6 +944,24 @@ template <typename T, typename TS> struct Impl {
     int egrid;
     if (mask & SL_ROWS) {
       ScopedTimer tm(c, 6, s);
+      // matrix-core form (rows_mfma.h): 16 rows per wave, the three K x V products of a row block as 16x16x4 matrix instructions on
+      // register-resident operands; K <= 32, V <= 64.  GDRF_ROWS_MFMA=0: the one-thread-per-row kernel (which serves the other sizes)
+      static const bool rows_mfma = !(getenv("GDRF_ROWS_MFMA") && getenv("GDRF_ROWS_MFMA")[0] == '0');
+      if (rows_mfma && K <= 32 && V <= 64) {
+        const int nkt = K <= 16 ? 1 : 2, nvt = V <= 32 ? 2 : 4;
+        const size_t lds = rows_mfma_lds<T>(K, V, nkt, nvt, 4);
+        const int64_t groups = (n + 15) / 16;
+        egrid = (int)std::min<int64_t>((groups + 3) / 4, c->erows_grid_cap);
+#define GDRF_RM(KT, VT) { if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)elbo_rows_mfma_kernel<T, KT, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                          hipLaunchKernelGGL((elbo_rows_mfma_kernel<T, KT, VT>), dim3(egrid), dim3(256), lds, s, n, K, V, c->hyp, P(c->qpart), nct<TS>(c), P(c->loc), P(c->tt), eps, ldk, n, ws, \
+                                             P(c->phi), (const T*)c->mean, c->mean_sk, c->mean_sn, P(c->q), P(c->vbar), P(c->locbar), P(c->asum), P(c->mu), c->dpart, P(c->phibar_part)); }
+        if (nkt == 1) { if (nvt == 2) GDRF_RM(1, 2) else GDRF_RM(1, 4) } else { if (nvt == 2) GDRF_RM(2, 2) else GDRF_RM(2, 4) }
+#undef GDRF_RM
+        LAUNCHCHK("elbo_rows (mfma)");
+        hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, (int64_t)egrid, 4, redd);
+        hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
+                           (int64_t)K * V, redT + roff(c, 1));
+      } else {
       const bool kreg = K <= GDRF_KMAX;
       auto lds_for = [&](int rb, bool wsep) {
         return 128 + ((size_t)2 * K * V + (size_t)rb * (K + 1) * (kreg ? 1 : 2) + (size_t)rb * (V + 1) * (wsep ? 2 : 1)) * sizeof(T);
@@ -970,6 +989,7 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, (int64_t)egrid, 4, redd);
       hipLaunchKernelGGL(reduce_parts_kernel<T>, dim3((K * V + 255) / 256), dim3(256), 0, s, P(c->phibar_part), (int64_t)egrid,
                          (int64_t)K * V, redT + roff(c, 1));
+      }
     }
     if (!(mask & SL_BACKWARD)) return 0;
     if constexpr (std::is_same<T, float>::value) {
@@ -1305,7 +1325,7 @@ template <typename T, typename TS> struct Impl {
       const size_t lds = 128 + ((size_t)M4 * DDt + (size_t)K * V + (size_t)4 * 16 * (16 * NB + 1)) * sizeof(TS);
       if (mfma_on && K <= 32 && lds <= 64 * 1024) {
         const int ldc = 16 * NB;
-        hipLaunchKernelGGL((predict_coeff_t_kernel<TS, T>), dim3((M4 + 127) / 128, ldc), dim3(128), 0, s, (const TS*)Q(c->Linv), U, M, Mp, M4, K, ldc, Q(c->CfT));
+        hipLaunchKernelGGL((predict_coeff_t_kernel<TS, T>), dim3(M4), dim3(64), 0, s, (const TS*)Q(c->LinvT), U, M, Mp, M4, K, ldc, Q(c->CfT));
         const int64_t groups = (n + 15) / 16;
         int64_t blocks = (groups + 3) / 4; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
         const int64_t ldo = mode == 0 ? n : (mode == 1 ? K : V);

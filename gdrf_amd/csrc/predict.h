@@ -15,15 +15,28 @@
 
 namespace gdrf {
 
-// CfT[i][c] = (L^-T u_c)[i] for c < K, 0 for the padding (i >= M or c >= K); ldc = 16 NB
+// CfT[i][c] = (L^-T u_c)[i] = sum_{j >= i} LinvT[i][j] u_c[j] for c < K, 0 for the padding (i >= M or c >= K); ldc = 16 NB <= 32.
+// One wave per inducing point: the lanes stride along the contiguous row i of LinvT, K running sums per lane, one wave reduction each.
 template <typename T, typename TN>
-__global__ void predict_coeff_t_kernel(const T* __restrict__ Linv, const TN* __restrict__ U, int M, int Mp, int M4, int K, int ldc, T* __restrict__ CfT) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-  if (i >= M4) return;
-  double s = 0;
-  if (i < M && k < K)
-    for (int j = i; j < M; ++j) s += (double)Linv[(int64_t)j * Mp + i] * (double)U[(int64_t)k * M + j];
-  CfT[(int64_t)i * ldc + k] = (T)s;
+__global__ __launch_bounds__(64) void predict_coeff_t_kernel(const T* __restrict__ LinvT, const TN* __restrict__ U, int M, int Mp, int M4, int K, int ldc,
+                                                             T* __restrict__ CfT) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  double acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc[k] = 0;
+  if (i < M)
+    for (int j = i + lane; j < M; j += 64) {
+      const double l = (double)LinvT[(int64_t)i * Mp + j];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) if (k < K) acc[k] += l * (double)U[(int64_t)k * M + j];
+    }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    if (k < ldc) {
+      const double s = (k < K) ? wave_sum(acc[k]) : 0.0;
+      if (lane == 0) CfT[(int64_t)i * ldc + k] = (T)s;
+    }
+  }
 }
 
 // mode 0: loc (K, n) ; 1: topic_probs (n, K) ; 2: word_probs (n, V) ; 3: perplexity partial sums {sum w log p, sum w} per workgroup

@@ -90,11 +90,18 @@ def test_full_size_configuration(name):
                                            n_global=N, chunk=cfg["chunk"], grad_names=("u_loc", "phi_unc", "log_noise"))
     print(f"{name}: chunked fp64 oracle {time.time() - t0:.1f} s, loss {loss_ref:.10f} vs HIP {out['loss']:.10f}, jitter level {level}")
     assert abs(out["loss"] - loss_ref) <= cfg["ltol"] * abs(loss_ref), (out["loss"], loss_ref)
+    # float32 arrays: mu = loc + v eps is stored with 24 bits, so the softmax weights carry a relative error of |mu| 2^-24 whatever
+    # computes them (tests/test_gpu_round3.py, regime "init": u_scale_tril = L_uu + noise makes |mu| as large as cond(K_uu))
+    gtol = cfg["gtol"]
+    if cfg["dtype"] == torch.float32:
+        mu_res = float(eng.workspace("mu", N).abs().max()) * 2.0 ** -24
+        gtol = max(gtol, 6.0 * mu_res)
+        print(f"  float32 resolution of mu: {mu_res:.2e} -> gradient bound {gtol:.2e}")
     for pname, g in got.items():
         r = grads_ref[pname].double()
         err = float((g - r).abs().max() / r.abs().max())
         print(f"  grad {pname}: rel err {err:.2e}")
-        assert err <= cfg["gtol"], (pname, err)
+        assert err <= gtol, (pname, err)
     # ---- linearity over a ragged row split
     h = N // 2 - 32 + 77
     parts_T, parts_d = torch.zeros_like(full_T), torch.zeros_like(full_d)
