@@ -37,7 +37,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_F64_MFMA_TFLOPS = 78.6      # v_mfma_f64_16x16x4_f64: half the f32 MFMA rate
 PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / f16 dense peak (16x the f32 MFMA rate)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
-PROFILE_ROUND = "r02"            # profiles/<round>/pmc_hbm.json: HBM bytes per launch from the PMC passes of this command
+PROFILE_ROUND = "r03"            # profiles/<round>/pmc_hbm.json: HBM bytes per launch from the PMC passes of this command
 SPLIT_PRODUCTS = {"bf16x6": 6, "f16x3": 3}     # MFMA products issued per f32 multiply-add (csrc/gemm_split.h)
 
 
@@ -65,6 +65,18 @@ def parse():
                          "fp16 pieces, 3 products, block-scaled - the default for float32; bf16x6: three bf16 pieces, 6 products), "
                          "or native f32 MFMA")
     return ap.parse_args()
+
+
+def csrc_sha():
+    """Fingerprint of the kernel sources (as tools/pmc_to_json.py writes it into pmc_hbm.json): PMC traffic collected on other sources
+    is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gdrf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def lattice_shape(n):
@@ -267,7 +279,8 @@ def main():
             pipe, peak, nprod = ("bf16" if eng.mfma_mode == "bf16x6" else "f16"), PEAK_16BIT_MFMA_TFLOPS, SPLIT_PRODUCTS[eng.mfma_mode]
         else:
             pipe, peak, nprod = ("f32" if dtype == torch.float32 else "f64"), (PEAK_F32_MFMA_TFLOPS if dtype == torch.float32 else PEAK_F64_MFMA_TFLOPS), 1
-        issued = tile_factor.get(dom, 1.0) * nprod * f32_equiv        # MFMA flops actually issued per second, in TFLOP/s
+        issued = nprod * f32_equiv        # MFMA flops the algorithm needs on this pipe per second (products per multiply-add x useful f32 flops), TFLOP/s
+        issued_tiles = tile_factor.get(dom, 1.0) * issued      # including the work above the diagonal that whole tiles execute
         f16 = eng.mfma_mode == "f16x3"
         kname = {"fwd_t": "fwd_t_split_q4_kernel" if f16 else "fwd_t_split_cc_kernel",
                  "bwd_wbar": "bwd_wbar_f16_k64_kernel" if f16 else "bwd_wbar_split_kernel",
@@ -279,7 +292,9 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_hbm.json")))
             ent = pm["kernels"].get(dom)
-            if ent and pm.get("mfma_mode") == eng.mfma_mode and pm.get("N") == N and world == 1:
+            if pm.get("csrc_sha") != csrc_sha():
+                traffic_note = "profiles/%s/pmc_hbm.json was collected on other kernel sources (csrc_sha differs): stale, not reported" % PROFILE_ROUND
+            elif ent and pm.get("mfma_mode") == eng.mfma_mode and pm.get("N") == N and world == 1:
                 traffic = ent["traffic_bytes"]
                 traffic_note = pm.get("note", "")
             else:
@@ -307,10 +322,12 @@ def main():
                          "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "algorithmic_flops_per_launch": flops[dom], "issued_flops_per_launch": tile_factor.get(dom, 1.0) * nprod * flops[dom],
-                         "products_per_f32_mac": nprod, "tile_granularity_factor": tile_factor.get(dom, 1.0), "avg_ms": ms[dom],
+                         "products_per_f32_mac": nprod, "tile_granularity_factor": tile_factor.get(dom, 1.0),
+                         "frac_including_whole_tile_overcompute": issued_tiles / peak, "avg_ms": ms[dom],
                          "f32_equivalent_tflops": f32_equiv, "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS,
-                         "note": "achieved = MFMA flops the kernel issues per second on the pipe it runs on (algorithmic f32 flops x "
-                                 "products per multiply-add x whole-tile factor); f32_equivalent_tflops = algorithmic f32 flops / time"},
+                         "note": "achieved = USEFUL MFMA flops per second on the pipe the kernel runs on (algorithmic f32 flops x products per "
+                                 "multiply-add; work above the diagonal that whole tiles execute is NOT counted - frac_including_whole_tile_overcompute "
+                                 "has it); f32_equivalent_tflops = algorithmic f32 flops / time"},
             "roofline_knm": {"bound": "hbm", "kernel": "knm_kernel<f32> (standalone, the metric's K_nm kernel)", "achieved": knm_gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": knm_gbs / PEAK_HBM_GBS, "traffic": knm_bytes,
                              "traffic_note": "WRITE_SIZE of this kernel equals its algorithmic bytes (profiles/%s/pmc_hbm.json, k_nm_f32)" % PROFILE_ROUND,

@@ -357,6 +357,9 @@ int gdrf_stores_t(const gdrf_ctx* c) { return c->Tst != nullptr; }
 int gdrf_set_mfma_mode(gdrf_ctx* c, int mode) {
   if (mode < 0 || mode > 2) return fail(-1, "gdrf_set_mfma_mode", "mode");
   if (mode != 0 && (c->esz != 4 || c->Tst)) return fail(-1, "gdrf_set_mfma_mode", "the split modes need float arrays and the dense Wbar form");
+  // f16x3 scales W by the bound |w| <= sqrt(variance), which the f64 solve guarantees (4x headroom); an all-fp32 solve of an ill-conditioned
+  // K_uu can break it and the fp16 pieces would overflow to inf without a trace: bf16x6 (f32's exponent range) is the split mode there
+  if (mode == 2 && c->ssz != 8) return fail(-1, "gdrf_set_mfma_mode", "f16x3 needs the f64 solve (GDRF_F32); use bf16x6 or f32 with GDRF_F32_PURE");
   HIPCHK(hipSetDevice(c->dev));
   const int np = mode == 1 ? 3 : (mode == 2 ? 2 : 0);
   if (np > c->wh_pieces) {            // 16-bit pieces of W: np x n_cap x Mp halfwords, allocated on first use
@@ -625,6 +628,7 @@ template <typename T, typename TS> struct Impl {
       const int rt8 = (int)((pairs + 7) / 8);
       FwdTSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * Mp, n, Mp, K, KG, rt8, (const E*)c->STh, nb, (float*)c->tt, c->ldk, (const float*)c->ssc, nullptr};
       constexpr int lds2 = 6 * SplitCfg<SP>::IMG * 2;
+#ifdef GDRF_DIAG   // diagnostic builds only (make DIAG=1): these paths synchronise the stream and allocate inside the step
       if (getenv("GDRF_STAMP")) {           // diagnostic: per-phase s_memtime stamps of one workgroup (tools/), never in a timed run
         unsigned long long* d = nullptr;
         HIPCHK(hipMalloc((void**)&d, 2 * 64 * 4 * 8)); HIPCHK(hipMemset(d, 0, 2 * 64 * 4 * 8));
@@ -670,6 +674,7 @@ template <typename T, typename TS> struct Impl {
           return 0;
         }
       }
+#endif
       const char* alt = getenv("GDRF_FWDT_ALTERNATING");          // A/B knob: the phase-alternating form
       if (alt && alt[0] == '1') {
         HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
@@ -732,6 +737,7 @@ template <typename T, typename TS> struct Impl {
         const char* alt = getenv("GDRF_WBAR_ALTERNATING");          // A/B knob: the phase-alternating form
         const size_t tabb = ((size_t)K * GDRF_TILE * sizeof(float) + 15) & ~(size_t)15;
         const size_t lds_cc = 6 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb;
+#ifdef GDRF_DIAG
         if (getenv("GDRF_STAMP_WBAR")) {      // diagnostic: per-phase s_memtime stamps of one workgroup, never in a timed run
           unsigned long long* d = nullptr;
           HIPCHK(hipMalloc((void**)&d, 2 * 64 * 4 * 8)); HIPCHK(hipMemset(d, 0, 2 * 64 * 4 * 8));
@@ -752,12 +758,19 @@ template <typename T, typename TS> struct Impl {
             fprintf(stderr, "wbar_cc stamps group %d: mean dma-issue %.0f mult %.0f vmcnt %.0f barrier %.0f | dma/mult/vmcnt/barrier per phase:%s\n", gpi, sd / cnt,
                     sm / cnt, sv / cnt, sb / cnt, line.c_str());
           }
-        } else if (std::is_same<SP, SplitF16>::value && !(alt && alt[0] != '0') && K >= 2 && (Mp % 64) == 0 &&
+        } else
+#endif
+        if (std::is_same<SP, SplitF16>::value && !(alt && alt[0] != '0') && K >= 2 && (Mp % 64) == 0 &&
                    8 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb <= 160 * 1024) {
           if constexpr (std::is_same<SP, SplitF16>::value) {
             const size_t lds64 = 8 * (size_t)SplitCfg<SP>::IMG * 2 + 2 * tabb;
-            const char* ab = getenv("GDRF_WBAR_ABLATE");         // timing-only diagnostic variants (wrong results)
+#ifdef GDRF_DIAG
+            const char* ab = getenv("GDRF_WBAR_ABLATE");         // timing-only variants with WRONG results: diagnostic builds only
             const int abl = ab ? atoi(ab) : 0;
+            if (abl) { static bool warned = false; if (!warned) { warned = true; fprintf(stderr, "libgdrf_hip: GDRF_WBAR_ABLATE=%d is active - Wbar and every gradient are WRONG (timing-only build)\n", abl); } }
+#else
+            constexpr int abl = 0;
+#endif
             // few rows (streaming mini-batches): a handful of workgroups would each walk all K x Mp / 64 chunks one after the other
             // (0.19 ms at n = 64); the reduction blocks are split over gridDim.y slices into slabs, summed in a fixed order
             const int nkb = Mp / 64;
@@ -768,8 +781,11 @@ template <typename T, typename TS> struct Impl {
             if (nslice > 1) { a.slab = (float*)c->slab; a.slab_stride = (int64_t)round_up(n, 256) * Mp; a.nslice = nslice; }
 #define GDRF_K64(X) { HIPCHK(hipFuncSetAttribute((const void*)bwd_wbar_f16_k64_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64)); \
                       hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel<X>, dim3((unsigned)round_up(pairs * nct_, 8), (unsigned)nslice), dim3(512), lds64, s, a); }
+#ifdef GDRF_DIAG
             if (abl == 1) GDRF_K64(1) else if (abl == 2) GDRF_K64(2) else if (abl == 3) GDRF_K64(3) else if (abl == 4) GDRF_K64(4)
-            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else GDRF_K64(0)
+            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else
+#endif
+            GDRF_K64(0)
 #undef GDRF_K64
             if (nslice > 1) {
               const int64_t n4 = n * Mp / 4;

@@ -1501,8 +1501,12 @@ __global__ void reduce_dparts_kernel(const double* __restrict__ part, int64_t np
 }
 // The doubles of red_d travelling in the element type of the flat payload, so that ONE all-reduce carries the whole step
 // (SURVEY.md 8(e)).  double payload: copied.  float payload: d = p0 + p1 + p2 + p3 with 12-bit-mantissa pieces p0..p2 (the
-// remainder p3 keeps 24 bits): sums of <= 8 such pieces of similar magnitude are exact in float, so the reduced value is the
-// f64 sum to ~2^-48 (worst case, ranks whose values differ by > 2^9: the float rounding of the largest piece, 2^-24).
+// remainder p3 keeps 24 bits).  While the ranks' values of an entry have similar magnitude (within 2^9: the loss sums red_d[0..8),
+// which every rank accumulates over its share of the rows) the float sums of the pieces over <= 8 ranks are exact and the reduced
+// value is the f64 sum to ~2^-48.  When they differ by more - the inducing-input sums red_d[8..) of spatially sharded rows can, and
+// can cancel - the sum of the leading pieces rounds at 2^-24 of the LARGEST summand and depends on the reduction order: float32
+// resolution of the largest contribution, which is what the float32 gradient it ends in resolves anyway
+// (tests/test_gpu_round3.py::test_packed_payload_with_rank_dependent_magnitudes).
 template <typename T>
 __global__ void payload_pack_kernel(const double* __restrict__ d, int nd, T* __restrict__ tail) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

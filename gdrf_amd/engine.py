@@ -422,8 +422,9 @@ class Engine:
             self.red_d.copy_(torch.stack(ds).mean(0))
         self.red_d[7:8].copy_(llc)                   # the data constant is a sum over observations too; stays on the device
         if dist_on:
-            # ONE collective per step: the doubles of red_d ride in the tail of the flat payload (exactly in float64 contexts,
-            # as four 12-bit-mantissa float pieces each in float32 ones, whose sums over <= 8 ranks are exact in float32)
+            # ONE collective per step: the doubles of red_d ride in the tail of the flat payload (exactly in float64 contexts; as four
+            # float pieces each in float32 ones: exact over <= 8 ranks for the loss sums, whose per-rank values have similar magnitude,
+            # and to 2^-24 of the largest summand for entries that differ by orders of magnitude between ranks - csrc/kernels_n.h)
             _lib.check(self.lib.gdrf_payload_pack(self.ctx, self.red_T.data_ptr(), self.red_d.data_ptr(), s), "gdrf_payload_pack")
             dist.all_reduce(self.red_T, group=pg)    # RCCL over xGMI (backend "nccl" on ROCm)
             _lib.check(self.lib.gdrf_payload_unpack(self.ctx, self.red_T.data_ptr(), self.red_d.data_ptr(), s), "gdrf_payload_unpack")

@@ -93,7 +93,8 @@ int gdrf_param_layout(const gdrf_ctx* ctx, int64_t out[7]);
 int gdrf_red_layout(const gdrf_ctx* ctx, int64_t out[6]);
 /* The step's ONE collective ("one ncclAllReduce(sum) per step over a flat buffer"): gdrf_payload_pack copies the
  * 8 + M*D doubles of red_d into the tail of red_T (total_T of gdrf_red_layout includes it) in red_T's element type - as they
- * are for double contexts, as four float pieces each (12 + 12 + 12 + 24 mantissa bits, so their sums over <= 8 ranks are exact)
+ * are for double contexts, as four float pieces each (12 + 12 + 12 + 24 mantissa bits: sums over <= 8 ranks are exact while the
+ * ranks' values of an entry lie within 2^9 of each other, as the loss sums do, and accurate to 2^-24 of the largest summand otherwise)
  * for float ones -; the caller all-reduces red_T alone and gdrf_payload_unpack restores red_d from the reduced tail. */
 int gdrf_payload_pack(gdrf_ctx* ctx, void* red_T_dev, const double* red_d_dev, void* stream);
 int gdrf_payload_unpack(gdrf_ctx* ctx, const void* red_T_dev, double* red_d_dev, void* stream);

@@ -4,8 +4,20 @@
 usage: pmc_to_json.py <dir with w/ and f/ counter dirs> <bench json log of the same configuration> > profiles/rNN/pmc_hbm.json
 WRITE_SIZE and FETCH_SIZE are in KB, collected in SEPARATE passes (TCC slot budget); per MI355X_MICROARCH.md (HBM) FETCH_SIZE
 reports half of a wide coalesced read stream on gfx950 (doubled here), WRITE_SIZE is exact for 16-byte streaming stores."""
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha():
+    """Fingerprint of the kernel sources the counters were collected on (bench.py refuses a pmc_hbm.json taken on other sources)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gdrf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 # timing slot -> substrings of the kernel names that can fill it (the first kernel found wins; one of them runs per configuration)
 SLOT = {"bwd_wbar": ("bwd_wbar_f16_k64_kernel", "bwd_wbar_split"), "fwd_t": ("fwd_t_split",), "tn_sym": ("tn_topics_f16_kernel",),
@@ -26,7 +38,7 @@ def main():
     root, bench_log = sys.argv[1], sys.argv[2]
     d = json.loads([l for l in open(bench_log) if l.startswith("{")][-1])
     w, f = means(os.path.join(root, "w"), "WRITE_SIZE"), means(os.path.join(root, "f"), "FETCH_SIZE")
-    out = {"N": d["config"]["N"], "mfma_mode": d["config"]["mfma_mode"], "kernels": {},
+    out = {"N": d["config"]["N"], "mfma_mode": d["config"]["mfma_mode"], "csrc_sha": csrc_sha(), "kernels": {},
            "note": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE in separate passes of `bench.py --steps 1`, mean per dispatch; "
                    "traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE counts half of a wide read stream on gfx950)"}
     for slot, pats in SLOT.items():
