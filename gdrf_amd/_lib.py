@@ -21,6 +21,8 @@ SIGNATURES = {
     "gdrf_stores_t": (_int, [_vp]),
     "gdrf_set_mfma_mode": (_int, [_vp, _int]),
     "gdrf_get_mfma_mode": (_int, [_vp]),
+    "gdrf_set_hyper_backward": (_int, [_vp, _int]),
+    "gdrf_get_hyper_backward": (_int, [_vp]),
     "gdrf_set_whiten": (_int, [_vp, _int]),
     "gdrf_set_mean": (_int, [_vp, _vp, _i64, _i64]),
     "gdrf_set_learn_inducing": (_int, [_vp, _int]),

@@ -9,6 +9,7 @@
 #include "kernels_n.h"
 #include "predict.h"
 #include "rows_mfma.h"
+#include "hyper_tn.h"
 
 #include <algorithm>
 #include <cmath>
@@ -62,6 +63,8 @@ struct gdrf_ctx {
   const void* mean_g; int64_t mean_g_sk, mean_g_sn;
   void *Wd;                   // W' = (dK_nm / d log lengthscale) Linv^T, allocated on first use (fixed inducing inputs, kernels without a third hyper-parameter)
   double* wdpart; hipEvent_t ev_wd;
+  void* dKh; hipStream_t side2; hipEvent_t ev_ak, ev_ak_done;    // pieces of dK_nm / d log ls (hyper_tn.h), allocated on first use; third stream: A_k beside the f64 backward GEMM
+  int hyper_tn; double* hpart;   // K_nm parts of the hyper-parameter gradients through Hd = dK^T Wbar on the TN kernel (hyper_tn.h) instead of the f64 backward GEMM
   void *Bh, *STh, *Wh;        // 16-bit pieces of B_k, S_k^T and W (f32 contexts; split-operand MFMA forms, gemm_split.h)
   int split;                  // 0: native f32 MFMA; 1: "bf16x6" (3 bf16 pieces, 6 products); 2: "f16x3" (2 fp16 pieces, 3 products, block scales)
   int wh_pieces;              // pieces Wh has room for
@@ -194,6 +197,11 @@ static bool wd_path(const gdrf_ctx* c) {
   const char* e = getenv("GDRF_WD_PATH");
   return e && e[0] == '1';
 }
+// K_nm parts of the hyper-parameter gradients through Hd = dK^T Wbar on the split-fp16 TN kernel (hyper_tn.h): f16x3 contexts with the f64
+// solve, fixed inducing inputs (their gradient needs Kbar itself), kernels whose only shape parameter is the lengthscale
+static bool hyper_tn_on(const gdrf_ctx* c) {
+  return c->hyper_tn && c->split == 2 && c->ssz == 8 && !c->learn_z && c->kind != GDRF_RATIONALQUADRATIC && !c->Tst && (c->Mp / 8) <= 256 && !wd_path(c);
+}
 static int tn_topics_nsplit(const gdrf_ctx* c, int64_t n) {
   if (const char* e = getenv("GDRF_TNT_NSPLIT")) { const int v = atoi(e); if (v > 0) return v; }
   const int units = tnt_ntiles(c->Mp) * ((c->K + TNT_KT - 1) / TNT_KT);
@@ -229,7 +237,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->split = 0; c->wh_pieces = 0; c->ssc = nullptr; c->smx = nullptr;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0; c->mean = nullptr; c->mean_sk = c->mean_sn = 0;
-  c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr; c->g_loc = nullptr; c->mean_g = nullptr; c->mean_g_sk = c->mean_g_sn = 0;
+  c->hyper_tn = 0; c->hpart = nullptr; c->dKh = nullptr; c->side2 = nullptr; c->ev_ak = c->ev_ak_done = nullptr; c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr; c->g_loc = nullptr; c->mean_g = nullptr; c->mean_g_sk = c->mean_g_sn = 0;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -269,7 +277,8 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   }
   c->nsplit_cap = tn_nsplit(c, n_cap, (int)(128 / c->esz));
   if (c->esz == 4) c->nsplit_cap = std::max({c->nsplit_cap, tn_nsplit(c, n_cap, 32, 2), tn_nsplit_gt(c, n_cap, 32), 64});   // the split TN forms run 2 workgroups per CU; the all-topics form up to 64 splits
-  AL(c->slab, (size_t)c->nsplit_cap * (K + 1) * mm)
+  AL(c->slab, (size_t)c->nsplit_cap * (K + 2) * mm)          // K batches of A_k, one of G^T, one of Hd = dK^T Wbar
+  AL(c->hpart, (size_t)std::max(4096, c->Mp + 2048) * sizeof(double))
   c->ubar_blocks_cap = std::min<int64_t>(1025, (n_cap + 255) / 256);     // upper bound of ubar_blocks(n) over n <= n_cap
   AL(c->ubar_part, (size_t)c->ubar_blocks_cap * K * c->Mp * c->esz)
   c->erows_grid_cap = 1024;
@@ -295,8 +304,9 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
       HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     }
   }
-  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact, &c->ev_wd})
+  for (hipEvent_t* e : {&c->ev_fork, &c->ev_loc, &c->ev_fork2, &c->ev_join, &c->ev_fact0, &c->ev_fact, &c->ev_wd, &c->ev_ak, &c->ev_ak_done})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
   HIPCHK(hipMemset(c->flag, 0, 128));
   HIPCHK(hipMemset(c->W, 0, (size_t)n_cap * c->Mp * c->esz));
   std::vector<double> a((size_t)K * V, 1.0);
@@ -310,8 +320,9 @@ void gdrf_ctx_destroy(gdrf_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& t : c->tev) { (void)hipEventDestroy(t.second.first); (void)hipEventDestroy(t.second.second); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join, c->ev_fact0, c->ev_fact, c->ev_wd}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev_fork, c->ev_loc, c->ev_fork2, c->ev_join, c->ev_fact0, c->ev_fact, c->ev_wd, c->ev_ak, c->ev_ak_done}) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->side2) (void)hipStreamDestroy(c->side2);
   delete c;
 }
 
@@ -416,6 +427,12 @@ int gdrf_set_learn_inducing(gdrf_ctx* c, int on) {
   return 0;
 }
 int gdrf_get_mfma_mode(const gdrf_ctx* c) { return c->split; }
+int gdrf_set_hyper_backward(gdrf_ctx* c, int mode) {
+  if (mode != 0 && mode != 1) return fail(-1, "gdrf_set_hyper_backward", "mode must be 0 (f64 backward GEMM) or 1 (Hd = dK^T Wbar on the TN kernel)");
+  c->hyper_tn = mode;
+  return 0;
+}
+int gdrf_get_hyper_backward(const gdrf_ctx* c) { return hyper_tn_on(c) ? 1 : 0; }
 int gdrf_ws_elem_size(gdrf_ctx* c, int which) { void* p; int64_t n; int e; return ws_lookup(c, which, &p, &n, &e) ? -1 : e; }
 
 int gdrf_set_timing(gdrf_ctx* c, int enable) {
@@ -703,11 +720,12 @@ template <typename T, typename TS> struct Impl {
   // sidx_b / sidx_b_stride: SplitLay pair index of the block scale of the row-scaled B operand (per batch)
   template <class SP>
   static int tn_split(gdrf_ctx* c, const float* B, const float* scale, int64_t scale_bs, int64_t n, int64_t rps, int sym, float* slab,
-                      int nbatch, int ns, int ntiles, int sidx_b, int sidx_b_stride, hipStream_t s) {
+                      int nbatch, int ns, int ntiles, int sidx_b, int sidx_b_stride, hipStream_t s, const void* Ah = nullptr, int sidx_a = -1) {
     if constexpr (std::is_same<T, float>::value) {
       using E = typename SP::E;
-      TNSplitArgs<SP> a{(const E*)c->Wh, (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns,
-                        (const float*)c->ssc, SplitLay{c->K}.w(), sidx_b, sidx_b_stride};
+      // stored (pre-split) operand: the pieces of W unless the caller names another [piece][row][Mp] array and its block scale
+      TNSplitArgs<SP> a{(const E*)(Ah ? Ah : c->Wh), (int64_t)c->ncap * c->Mp, c->Mp, B, c->Mp, scale, scale_bs, n, rps, c->Mp, sym, slab, nbatch, ns,
+                        (const float*)c->ssc, sidx_a >= 0 ? sidx_a : SplitLay{c->K}.w(), sidx_b, sidx_b_stride};
       constexpr int lds = 3 * SP::NP * 32 * 128 * 2;            // double-buffered A image + B image
       HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_split_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(gemm_tn_split_kernel<SP>, dim3((unsigned)(ntiles * nbatch * ns)), dim3(256), lds, s, a);
@@ -857,7 +875,7 @@ template <typename T, typename TS> struct Impl {
   // parts of one evaluation: the parameter transforms, the forward over the rows (K_nm, W, loc, tt), the per-row terms, the backward
   // over the rows.  gdrf_step_local runs them all; the two-point evaluation (step_local2: guide and model on different inputs) runs
   // them selectively.
-  enum { SL_TRANSFORMS = 1, SL_FORWARD = 2, SL_ROWS = 4, SL_BACKWARD = 8, SL_ALL = 15 };
+  enum { SL_TRANSFORMS = 1, SL_FORWARD = 2, SL_ROWS = 4, SL_BACKWARD = 8, SL_ALL = 15, SL_NO_DK = 16 /* forward for the predictive path: no backward follows */ };
   static int step_local(gdrf_ctx* c, const T* X, const int32_t* ws, const T* eps, int64_t n, const T* Z, const T* params,
                         T* redT, double* redd, hipStream_t s, int mask = SL_ALL) {
     const int Mp = c->Mp, M = c->M, K = c->K, V = c->V;
@@ -921,6 +939,26 @@ template <typename T, typename TS> struct Impl {
       }
     }
     HIPCHK(hipEventRecord(c->ev_loc, c->side));
+    if constexpr (std::is_same<T, float>::value && sizeof(TS) == 8) {
+      if (hyper_tn_on(c) && !(mask & SL_NO_DK)) {
+        // pieces of dK_nm / d log(lengthscale) for the backward's Hd = dK^T Wbar; on the side stream behind loc: the main stream does not wait for it
+        const int vpr = Mp / 8, rpp = 256 / vpr;
+        const int64_t blocks = std::min<int64_t>((n + rpp - 1) / rpp, 256 * 16);
+        if (!c->dKh) {
+          void* pw = nullptr;
+          hipError_t e = hipMalloc(&pw, (size_t)2 * c->ncap * Mp * 2);
+          if (e != hipSuccess) return fail(-(int)e - 1000, "hipMalloc(dKh)", hipGetErrorString(e));
+          c->dKh = pw; c->allocs.push_back(pw);
+        }
+        _Float16* dkh = (_Float16*)c->dKh;
+        const float* dsc = (const float*)c->ssc + SplitLay{K}.dk();
+        if (c->D <= 2) hipLaunchKernelGGL((dk_pieces_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, c->side, X, n, (const double*)c->Zs, M, c->D, c->kind, c->hyp, dkh,
+                                          (int64_t)c->ncap * Mp, Mp, dsc);
+        else hipLaunchKernelGGL((dk_pieces_kernel<T, GDRF_DMAX>), dim3((unsigned)blocks), dim3(256), 0, c->side, X, n, (const double*)c->Zs, M, c->D, c->kind, c->hyp, dkh,
+                                (int64_t)c->ncap * Mp, Mp, dsc);
+        LAUNCHCHK("dk_pieces");
+      }
+    }
     // W' = (dK_nm / d log lengthscale) Linv^T on the side stream, beside the K-fold contractions (its f64 MFMAs fill their stalls);
     // with it the K_nm parts of the hyper-parameter gradients are two dot products with Wbar (wbar_dot_kernel) and the backward
     // GEMM Kbar = Wbar Linv with its pass over K_nm is not needed
@@ -1087,7 +1125,31 @@ template <typename T, typename TS> struct Impl {
     }
     HIPCHK(hipEventRecord(c->ev_join, c->side));
     // (4) kernel hyper-parameter partials through K_nm
-    if (use_wd) {
+    bool hyper_done = false;
+    if constexpr (std::is_same<T, float>::value && sizeof(TS) == 8) {
+      if (hyper_tn_on(c)) {
+        // on the side stream, behind G^T: Hd = dK^T Wbar on the same TN kernel (slab batch K + 1), its contraction with L^-1 in double ->
+        // red_d[5]; sum Wbar o W -> red_d[4]; red_d[6] = 0.  No backward solve GEMM (hyper_tn.h).
+        hipStream_t ss = c->side;
+        ScopedTimer tm(c, 8, ss);
+        const int BR = TNCfg<T>::BR;
+        const int ns = std::min(tn_nsplit_gt(c, n, BR), c->nsplit_cap);
+        const int64_t rps = round_up((n + ns - 1) / ns, BR);
+        float* slab_hd = (float*)c->slab + (int64_t)c->nsplit_cap * (K + 1) * mm;
+        const SplitLay SL{K};
+        if ((rc = tn_split<SplitF16>(c, (const float*)c->Wbar, nullptr, 0, n, rps, 0, slab_hd, 1, ns, c->nt * c->nt, SL.wbar(), 0, ss, c->dKh, SL.dk()))) return rc;
+        hipLaunchKernelGGL(slab_linvt_dot_kernel<TS>, dim3((unsigned)M), dim3(256), 0, ss, (const float*)slab_hd, ns, Mp, M, (const TS*)Q(c->LinvT), c->hpart);
+        hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, ss, c->hpart, (int64_t)M, 1, redd + 5);
+        hipLaunchKernelGGL(wbar_w_dot_kernel<T>, dim3(2048), dim3(256), 0, ss, (const T*)P(c->Wbar), (const T*)P(c->W), n, Mp, c->hpart + Mp);
+        hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, ss, c->hpart + Mp, (int64_t)2048, 1, redd + 4);
+        HIPCHK(hipMemsetAsync(redd + 6, 0, sizeof(double), ss));
+        LAUNCHCHK("hyper_tn");
+        HIPCHK(hipEventRecord(c->ev_join, c->side));           // the join event now also covers these
+        hyper_done = true;
+      }
+    }
+    if (hyper_done) {
+    } else if (use_wd) {
       // on the side stream, behind W' and G^T / ubar: sum Wbar o W -> red_d[4], sum Wbar o W' -> red_d[5]; red_d[6] = 0
       hipStream_t ss = c->side;
       hipLaunchKernelGGL(wbar_dot_kernel<T>, dim3(2048), dim3(256), 0, ss, (const T*)P(c->Wbar), (const T*)P(c->W), (const T*)P(c->Wd), n, Mp, c->wdpart);
@@ -1115,7 +1177,16 @@ template <typename T, typename TS> struct Impl {
       hipLaunchKernelGGL(reduce_dparts_kernel, dim3(1), dim3(1024), 0, s, c->dpart, nb, 3, redd + 4);      // red_d[4..6]
     }
     LAUNCHCHK("backward");
-    // (5) A_k = W^T diag(vbar_k) W and GT = W^T Wbar
+    // (5) A_k = W^T diag(vbar_k) W.  It needs W and vbar only - not Wbar - and could run on a third stream BESIDE the f64 backward GEMM
+    // (GDRF_AK_ASIDE=1).  Measured (profiles/r03): no gain - 48.57 vs 48.71 ms/step; the two kernels time-slice the CUs (A_k 9.2 -> 18.0 ms,
+    // bwd_knm 8.7 -> 10.7 ms beside each other) instead of filling each other's stalls as the register-capped G^T kernel does.  Off.
+    static const bool ak_aside = getenv("GDRF_AK_ASIDE") && getenv("GDRF_AK_ASIDE")[0] == '1';
+    const bool ak_on_side = ak_aside && !hyper_done && !use_wd && c->split == 2 && sizeof(TS) == 8;
+    hipStream_t s_main = s;
+    if (ak_on_side) {
+      HIPCHK(hipStreamWaitEvent(c->side2, c->ev_fork2, 0));       // recorded on the caller's stream right behind the Wbar contraction
+      s = c->side2;
+    }
     {
       const int BR = TNCfg<T>::BR;
       const int ns = std::min(tn_nsplit(c, n, BR, c->split ? 2 : 3), c->nsplit_cap);
@@ -1149,6 +1220,11 @@ template <typename T, typename TS> struct Impl {
       { ScopedTimer tm(c, 11, s);
         dim3 gr((Mp + 255) / 256, Mp, K);
         hipLaunchKernelGGL(reduce_slabs_kernel<T>, gr, dim3(256), 0, s, P(c->slab), red_ns, K, Mp, 1, redT + roff(c, 2), red_qd); }
+    }
+    if (ak_on_side) {
+      HIPCHK(hipEventRecord(c->ev_ak_done, c->side2));
+      s = s_main;
+      HIPCHK(hipStreamWaitEvent(s, c->ev_ak_done, 0));
     }
     HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     LAUNCHCHK("reductions");
@@ -1326,7 +1402,7 @@ template <typename T, typename TS> struct Impl {
       // (f_loc, f_var) of gp.util.conditional(full_cov=False) (gdrf/models/sparse_gdrf.py:277-319): the step's own forward - transforms,
       // K_nm, W = K_nm L^-T with its row norms, loc = W U^T, tt = |S_k^T w|^2 - and one pass that assembles the variance
       if (n > c->ncap) return fail(-1, "gdrf_predict", "mode 4 (loc, var) needs n <= n_cap");
-      if (int rc = step_local(c, X, nullptr, nullptr, n, Z, params, nullptr, nullptr, s, SL_TRANSFORMS | SL_FORWARD)) return rc;
+      if (int rc = step_local(c, X, nullptr, nullptr, n, Z, params, nullptr, nullptr, s, SL_TRANSFORMS | SL_FORWARD | SL_NO_DK)) return rc;
       hipLaunchKernelGGL(predict_var_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, K, c->hyp, (const T*)P(c->qpart), nct<TS>(c),
                          (const T*)P(c->loc), (const T*)P(c->tt), c->ldk, out);
       LAUNCHCHK("predict (loc, var)");

@@ -40,6 +40,17 @@ template <> struct Mfma<double> {
   static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + (r << 2); }
 };
 
+// A raw s_barrier (no vmcnt drain: LDS-DMA requests stay in flight across it) that the COMPILER cannot move memory accesses across either.
+// The s_barrier intrinsic alone does not order ordinary LDS loads: hipcc may hoist a read that follows it in the source above it (after
+// the preceding `s_waitcnt` asm) - another wave's LDS stores of the phase before are then read before they were made.  Found in round 3:
+// an arithmetic-only edit of tn_topics_f16_kernel changed the schedule and produced run-to-run different results.  The empty asm with a
+// memory clobber on either side pins the accesses; the caller still waits for its own counters (lgkmcnt / vmcnt) in front.
+__device__ __forceinline__ void gdrf_raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- wave / block reductions -------------------------------------------------
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

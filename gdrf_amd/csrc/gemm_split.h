@@ -75,7 +75,8 @@ struct SplitLay {
   __host__ __device__ int b(int k) const { return 4 + 2 * k; }
   __host__ __device__ int st(int k) const { return 4 + 2 * K + 2 * k; }
   __host__ __device__ int v(int k) const { return 4 + 4 * K + 2 * k; }
-  __host__ __device__ int nfloats() const { return 4 + 6 * K; }
+  __host__ __device__ int dk() const { return 4 + 6 * K; }          // dK_nm / d log(lengthscale): from the bound |dK| <= 0.75 variance (hyper_tn.h)
+  __host__ __device__ int nfloats() const { return 6 + 6 * K; }
   __host__ __device__ int mx_wbar() const { return 0; }
   __host__ __device__ int mx_b(int k) const { return 1 + k; }
   __host__ __device__ int mx_st(int k) const { return 1 + K + k; }
@@ -99,6 +100,8 @@ __global__ void split_scales_kernel(int f16, const Hyper* __restrict__ h, const 
   const int t = threadIdx.x;
   if ((what & SPLIT_SC_W) && t == 0)          // |w_nj| <= ||w_n|| <= sqrt(k(x,x)) = sqrt(variance); 4x headroom for rounding in the solve
     put(L.w(), f16 ? split_pow2_scale(sqrtf((float)h->var), 13) : 1.0f);
+  // |dk / d log ls| <= 0.75 variance for every kernel kind (RBF: k r^2 <= 2/e var; Matern-5/2: 0.59 var; Matern-3/2: 0.54; exponential: 0.37)
+  if ((what & SPLIT_SC_W) && t == 0) put(L.dk(), f16 ? split_pow2_scale(0.75f * (float)h->var, 15) : 1.0f);
   if ((what & SPLIT_SC_WBAR) && t == 0) put(L.wbar(), f16 ? split_pow2_scale(__uint_as_float(mx[L.mx_wbar()]), 15) : 1.0f);
   for (int k = t; k < K; k += blockDim.x) {
     if (what & SPLIT_SC_BST) {
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256 * NG, 2) void bwd_wbar_split_kernel(BwdWbarSpli
     };
     auto phase_barrier = [&]() {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads are done; a DMA just issued stays in flight
-      __builtin_amdgcn_s_barrier();
+      gdrf_raw_barrier();
     };
     // Chunk t is multiplied by group 0 in phase 2t and by group 1 in phase 2t+1, both from B buffer t & 1 and their own A
     // image (whose fragments then stay in registers for the K topic reps).  DMAs are issued in a group's idle phase, land
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_split_cc_kernel(BwdWbarSplitA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(c, 3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    gdrf_raw_barrier();
   }
   if (STAMP) { if (stamping) for (int i = 0; i < 64 * 4; ++i) g.stamps[gp * 256 + i] = lstamp[gp * 256 + i]; }
   // rank-K epilogue term locbar^T U on the native f32 matrix instruction (exact f32, no split, no range question): lane
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    gdrf_raw_barrier();
   }
   // rank-K epilogue term locbar^T U on the native f32 matrix instruction (exact f32, no split, no range question): lane
   // (lr, lg) supplies A[row lr][k = lg] and B[k = lg][col lr] of v_mfma_f32_16x16x4_f32, whose C/D layout is the accumulators'
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_2g_kernel(FwdTSplitArgs<SP
   };
   auto phase_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    gdrf_raw_barrier();
   };
   dma_a(0);
   if (gp == 0) dma_a(1); else dma_b(0);
@@ -1218,7 +1221,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
   dma(0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  gdrf_raw_barrier();
   while (ct < nct) {
     // the chunk after this one: next k block of the column tile, or the first one (k = 128 ct') of the next column tile
     int ct1 = ct, kA1 = kA + CF::BK;
@@ -1266,7 +1269,7 @@ __global__ __launch_bounds__(512, 2) void fwd_t_split_cc_kernel(FwdTSplitArgs<SP
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's DMAs of the next chunk have landed (they had the whole phase)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    gdrf_raw_barrier();
     ct = ct1; kA = kA1; buf ^= 1;
   }
   // row sums: 16-lane groups, then the two waves of a group that share the rows, through LDS; the block scales come off here
@@ -1389,7 +1392,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
   for (int sl = 0; sl < 2 * NP; ++sl) dma1(0, 0, 0, sl);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  gdrf_raw_barrier();
   // Every chunk issues the requests of the chunk after it (the last one re-requests itself into the idle buffers: nobody reads them),
   // so the multiply loop has no branch around its DMAs; a group's idle chunks run in a loop of their own that never touches the
   // accumulators (with both in one loop body hipcc kept copies of them across the branch and spilled at 128 registers).
@@ -1413,7 +1416,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
 #pragma unroll
       for (int sl = 0; sl < 2 * NP; ++sl) dma1(cp1, kA1, buf ^ 1, sl);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      gdrf_raw_barrier();
       buf ^= 1;
     }
 #pragma unroll 1
@@ -1463,7 +1466,7 @@ __global__ __launch_bounds__(1024) void fwd_t_split_q4_kernel(FwdTSplitArgs<SP> 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of the next chunk have landed (they had the whole phase)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stamp(3);
-      __builtin_amdgcn_s_barrier();
+      gdrf_raw_barrier();
       stamp(4);
       if (VAR & 16) ++sphase;
       buf ^= 1;
@@ -1662,6 +1665,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
       for (int e = 0; e < 8; ++e) {
         E p[NP];
         SP::split(rb[2 * i + (e >> 2)][e & 3] * s, p);
+        // f16x3: the row-scaled operand's block scale comes from a maximum (an outlier statistic), the bulk of its entries sits many
+        // binades lower and their low piece would fall into fp16's subnormals: it is stored as l' = 2^11 l and multiplied with 2^-11 h_a
+        // (gemm_tn_topics.h has the measurement: 15 -> 22 bits on a contracted posterior)
+        if constexpr (SP::ID == 2) p[1] = (E)((rb[2 * i + (e >> 2)][e & 3] * s - (float)p[0]) * 2048.0f);
 #pragma unroll
         for (int q = 0; q < NP; ++q) pb[i][q][e] = p[q];
       }
@@ -1687,10 +1694,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
       V8 fa[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) fa[p] = frag(Ab + p * PIECE, xa[a]);
+      V8 fa2 = fa[0];
+      if constexpr (SP::ID == 2) fa2 = fa[0] * (E)0.00048828125f;          // 2^-11 h_a: partner of the B operand's up-scaled low piece (product 0 = h_a l_b)
 #pragma unroll
       for (int t2 = 0; t2 < SP::NPROD; ++t2)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[a][t] = SP::mma(fa[SP::pa(t2)], fb[SP::pb(t2)][t], acc[a][t]);
+        for (int t = 0; t < 4; ++t) acc[a][t] = SP::mma((SP::ID == 2 && t2 == 0) ? fa2 : fa[SP::pa(t2)], fb[SP::pb(t2)][t], acc[a][t]);
     }
   }
   if (idle) return;

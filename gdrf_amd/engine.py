@@ -34,7 +34,8 @@ class Engine:
 
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
                  device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
-                 store_t="auto", mfma_mode: str = "auto", learn_inducing: bool = False, whiten: bool = True):
+                 store_t="auto", mfma_mode: str = "auto", learn_inducing: bool = False, whiten: bool = True,
+                 hyper_backward: str = "auto"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -69,6 +70,13 @@ class Engine:
         self.mfma_mode = mfma_mode
         if mfma_mode != "f32":
             _lib.check(self.lib.gdrf_set_mfma_mode(self.ctx, {"bf16x6": 1, "f16x3": 2}[mfma_mode]), "gdrf_set_mfma_mode")
+        # K_nm parts of the kernel hyper-parameter gradients: "f64" (= "auto") = Kbar = Wbar L^-1 on the f64 matrix pipe; "tn" = Hd = dK^T Wbar
+        # on the split TN kernel + an M x M contraction with L^-1 in double (csrc/hyper_tn.h; no f64 backward GEMM: faster, but d / d log
+        # lengthscale then carries float32-level rounding through the cancelling contraction: 3.6e-4 instead of 1e-7 at the headline grid)
+        if hyper_backward not in ("auto", "tn", "f64"):
+            raise ValueError("hyper_backward must be 'auto', 'tn' or 'f64'")
+        _lib.check(self.lib.gdrf_set_hyper_backward(self.ctx, 1 if hyper_backward == "tn" else 0), "gdrf_set_hyper_backward")
+        self._hyper_backward_request = hyper_backward
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
         zl = (C.c_int64 * 2)()
@@ -104,6 +112,11 @@ class Engine:
         # a caller-supplied link (the reference's `link_function`, abstract_gdrf.py:34-50): a callable on the (K, n) tensor mu returning the
         # (K, n) topic weights; None = the softmax link fused into the row kernel.  Evaluated with torch between three library calls.
         self.link_function = None
+
+    @property
+    def hyper_backward(self) -> str:
+        """The form the next step uses ("tn" needs f16x3, fixed inducing inputs, a kernel other than RationalQuadratic)."""
+        return "tn" if self.lib.gdrf_get_hyper_backward(self.ctx) else "f64"
 
     def __del__(self):
         try:

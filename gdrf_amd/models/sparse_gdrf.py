@@ -166,6 +166,7 @@ class SparseMultinomialGDRF:
         dtype: torch.dtype = torch.float32,
         pure_fp32: bool = False,
         mfma_mode: str = "auto",
+        hyper_backward: str = "auto",
         inducing_points: Optional[torch.Tensor] = None,
         seed: Optional[int] = None,
         guide_rescale: bool = True,
@@ -199,6 +200,7 @@ class SparseMultinomialGDRF:
         self.dtype = dtype
         self._pure_fp32 = bool(pure_fp32)
         self._mfma_mode = mfma_mode          # Engine(mfma_mode=...): "auto" | "f32" | "bf16x6" | "f16x3"
+        self._hyper_backward = hyper_backward   # Engine(hyper_backward=...): "auto" | "tn" | "f64" (csrc/hyper_tn.h)
         self._kernel = kernel
         if kernel.input_dim != self._n_dims:
             raise ValueError("kernel.input_dim does not match the world's dimensionality")
@@ -245,7 +247,7 @@ class SparseMultinomialGDRF:
             return e
         new = Engine(n, self.M, self._K, self._V, self.D, dtype=self.dtype, kernel=self._kernel.name, device=self.device,
                      jitter=self._jitter, maxjitter=self._maxjitter, pure_fp32=self._pure_fp32, mfma_mode=self._mfma_mode,
-                     learn_inducing=not self._fixed_inducing_points, whiten=self._whiten)
+                     learn_inducing=not self._fixed_inducing_points, whiten=self._whiten, hyper_backward=self._hyper_backward)
         new.set_inducing_points(self._inducing_points)
         new.set_dirichlet(self._dirichlet_param)
         new.link_function = self._link_function

@@ -60,6 +60,16 @@ int gdrf_stores_t(const gdrf_ctx* ctx);
  * float32 with the f64 solve by default. */
 int gdrf_set_mfma_mode(gdrf_ctx* ctx, int mode);
 int gdrf_get_mfma_mode(const gdrf_ctx* ctx);
+/* How the K_nm parts of the kernel hyper-parameter gradients (sum Kbar_nm o K_nm, sum Kbar_nm o dK_nm/dlog ls) are formed:
+ *   0  (default) Kbar_nm = Wbar L^-1 tile by tile in the solve precision (gemm_nt<BwdKnmProb>, f64 matrix pipe), never stored;
+ *   1  no backward solve: sum Kbar o K = sum Wbar o W, and sum Kbar o dK = sum_{i>=j} Linv[i][j] Hd[j][i] with Hd = dK^T Wbar, an M x M
+ *      contraction over the rows on the split-fp16 TN kernel (csrc/hyper_tn.h), its contraction with L^-1 in double.  Applies to float arrays
+ *      in mode f16x3 with fixed inducing inputs and a kernel other than RationalQuadratic; every other configuration runs form 0.  Faster
+ *      (no f64 GEMM), but Hd carries float32-level rounding INTO the cancelling contraction with L^-1: d loss / d log lengthscale is then
+ *      accurate to ~4e-4 instead of ~1e-7 at the headline conditioning (tests/test_gpu_round3.py), hence opt-in.
+ * gdrf_get_hyper_backward reports the form the next step will actually use. */
+int gdrf_set_hyper_backward(gdrf_ctx* ctx, int mode);
+int gdrf_get_hyper_backward(const gdrf_ctx* ctx);
 /* whiten = 0: the unwhitened branch of pyro's gp.util.conditional (gdrf/models/sparse_gdrf.py:30,175-185: the
  * constructor's `whiten` argument): u_loc and u_scale_tril parameterise q(f(Z)) itself, the predictive uses
  * L^-1 u_loc and L^-1 u_scale_tril.  Default 1 (whitened), which is what the reference's train() always runs. */

@@ -38,14 +38,14 @@ def make_oracle(kind="rbf", W=16, H=9, V=20, K=4, n_points=(4, 3), dtype=torch.f
     return m, eps
 
 
-def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=False, store_t="auto", mfma_mode="auto"):
+def engine_from_oracle(m, dtype=None, device="cuda:0", n_cap=None, pure_fp32=False, store_t="auto", mfma_mode="auto", hyper_backward="auto"):
     """gdrf_amd.Engine holding exactly the oracle's parameters / inducing points / Dirichlet prior."""
     from gdrf_amd.engine import Engine
     dtype = m.dtype if dtype is None else dtype
     learn = bool(getattr(m, "learn_inducing", False))
     eng = Engine(n_cap or m.N, m.M, m.K, m.V, m.D, dtype=dtype, kernel=m.kind, device=device, jitter=m.jitter,
                  maxjitter=m.maxjitter, process_group=None, pure_fp32=pure_fp32, store_t=store_t, mfma_mode=mfma_mode,
-                 learn_inducing=learn, whiten=bool(getattr(m, "whiten", True)))
+                 learn_inducing=learn, whiten=bool(getattr(m, "whiten", True)), hyper_backward=hyper_backward)
     eng.set_inducing_points(m.Z)
     eng.set_dirichlet(m.alpha)
     load_params(eng, m)

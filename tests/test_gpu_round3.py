@@ -37,8 +37,8 @@ def _scalar_block(errs_abs, refs):
     return max(errs_abs[n] for n in names) / max(max(abs(refs[n]) for n in names), 1e-300)
 
 
-def _all_block_errors(m, eps, dtype, mfma_mode="auto"):
-    eng = engine_from_oracle(m, dtype=dtype, mfma_mode=mfma_mode)
+def _all_block_errors(m, eps, dtype, mfma_mode="auto", hyper_backward="auto"):
+    eng = engine_from_oracle(m, dtype=dtype, mfma_mode=mfma_mode, hyper_backward=hyper_backward)
     xs, ws = dev(m.xs, eng), dev(m.ws, eng, torch.int32)
     lvl = eng.factorize()                                # the level the engine's own (array-precision) probe asks for
     m.force_jitter_level = lvl
@@ -126,15 +126,18 @@ def test_config4_matern52_m1024_k20_all_gradient_blocks(dtype, regime):
 
 
 @pytest.mark.parametrize("regime", list(REGIMES))
-@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-tn", "bf16x6", "f32"])
 def test_headline_conditioning_all_gradient_blocks(mode, regime):
     """The headline workload's inducing grid and lengthscale (32 x 16, l = 0.1: cond(K_uu + jitter) ~ 1e7, the jitter level
-    escalates) at N = 3000, fp32 arrays, in the default f16x3 arithmetic and the two selectable ones."""
+    escalates) at N = 3000, fp32 arrays, in the default f16x3 arithmetic, the same with the opt-in hyper_backward="tn" (K_nm parts of the
+    hyper-parameter gradients through Hd = dK^T Wbar instead of the f64 backward GEMM, csrc/hyper_tn.h), and the two other arithmetics."""
     m, eps = make_oracle(kind="rbf", W=60, H=50, V=50, K=10, n_points=(32, 16), dtype=torch.float64, jitter=1e-6, lengthscale=0.1,
                          **REGIMES[regime])
-    lvl, errs, eng = _all_block_errors(_fp32_valued(m), eps, torch.float32, mfma_mode=mode)
+    mode, hb = (("f16x3", "tn") if mode == "f16x3-tn" else (mode, "auto"))
+    lvl, errs, eng = _all_block_errors(_fp32_valued(m), eps, torch.float32, mfma_mode=mode, hyper_backward=hb)
     assert eng.mfma_mode == mode
-    print("headline conditioning", mode, regime, "level", lvl, {k: f"{v:.2e}" for k, v in errs.items()})
+    assert eng.hyper_backward == ("tn" if hb == "tn" else "f64")
+    print("headline conditioning", mode, "hyper_backward", eng.hyper_backward, regime, "level", lvl, {k: f"{v:.2e}" for k, v in errs.items()})
     assert lvl >= 1
     _assert_fp32(errs, regime)
 
