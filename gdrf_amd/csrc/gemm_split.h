@@ -1668,7 +1668,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(96))) void g
         // f16x3: the row-scaled operand's block scale comes from a maximum (an outlier statistic), the bulk of its entries sits many
         // binades lower and their low piece would fall into fp16's subnormals: it is stored as l' = 2^11 l and multiplied with 2^-11 h_a
         // (gemm_tn_topics.h has the measurement: 15 -> 22 bits on a contracted posterior)
-        if constexpr (SP::ID == 2) p[1] = (E)((rb[2 * i + (e >> 2)][e & 3] * s - (float)p[0]) * 2048.0f);
+        if constexpr (SP::ID == 2) {
+          float r = rb[2 * i + (e >> 2)][e & 3] * s - (float)p[0];
+          asm volatile("" : "+v"(r));                  // keeps the SLP vectorizer off this arithmetic (gemm_tn_topics.h: split_pair)
+          p[1] = (E)(r * 2048.0f);
+        }
 #pragma unroll
         for (int q = 0; q < NP; ++q) pb[i][q][e] = p[q];
       }

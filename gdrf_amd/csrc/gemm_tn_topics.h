@@ -28,9 +28,6 @@
 
 namespace gdrf {
 
-#ifndef TNT_USE_FA2
-#define TNT_USE_FA2 1
-#endif
 constexpr int TNT_KT = 10;                    // topics per workgroup (accumulator budget)
 
 struct TNTopicsArgs {
@@ -135,12 +132,16 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       E p0[NP], p1[NP];
-      const float y0 = x[e] * v0, y1 = x[e] * v1;
-#ifndef TNT_LSCALE
-#define TNT_LSCALE 2048.0f
-#endif
-      p0[0] = (E)y0; p0[1] = (E)((y0 - (float)p0[0]) * TNT_LSCALE);          // l' = 2^11 l (see the header comment)
-      p1[0] = (E)y1; p1[1] = (E)((y1 - (float)p1[0]) * TNT_LSCALE);
+      // The values pass through empty asm statements so that hipcc's SLP vectorizer leaves this arithmetic scalar: the packed-f32 code
+      // (v_pk_mul_f32 / v_pk_fma_f32 with op_sel) it made of the four elements x two topics produced run-to-run different results
+      // with non-finite low pieces for the second topic of the slot split during phase 0 (ROCm 7.2; -fno-slp-vectorize for the whole
+      // library cures it too but costs bwd_wbar its packed accumulator updates: 48.1 -> 49.0 ms per step)
+      float y0 = x[e] * v0, y1 = x[e] * v1;
+      asm volatile("" : "+v"(y0), "+v"(y1));
+      p0[0] = (E)y0; p1[0] = (E)y1;
+      float r0 = y0 - (float)p0[0], r1 = y1 - (float)p1[0];
+      asm volatile("" : "+v"(r0), "+v"(r1));
+      p0[1] = (E)(r0 * 2048.0f); p1[1] = (E)(r1 * 2048.0f);               // l' = 2^11 l (see the header comment)
 #pragma unroll
       for (int s = 0; s < NP; ++s) { pv[0][s][e] = p0[s]; pv[1][s][e] = p1[s]; }
     }
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
 #pragma unroll
                       for (int b = 0; b < 2; ++b)
                         acc[(2 * (first + sl) + t) < KT ? 2 * (first + sl) + t : 0][a][b] =
-                            SP::mma((x == 0 && TNT_USE_FA2) ? fa2[a] : fa[a][SP::pa(x)], fb[b][SP::pb(x)], acc[(2 * (first + sl) + t) < KT ? 2 * (first + sl) + t : 0][a][b]);   // x = 0: (h_a, l_b)
+                            SP::mma(x == 0 ? fa2[a] : fa[a][SP::pa(x)], fb[b][SP::pb(x)], acc[(2 * (first + sl) + t) < KT ? 2 * (first + sl) + t : 0][a][b]);   // x = 0: (h_a, l_b)
                 }
               }
             }
