@@ -208,11 +208,16 @@ static int tn_topics_nsplit(const gdrf_ctx* c, int64_t n) {
   int64_t maxs = (n + 16 * 32 - 1) / (16 * 32);
   if (maxs > 64) maxs = 64;
   if (maxs < 1) maxs = 1;
-  int best = 1; double best_eff = 0;
+  // cost model (relative units): rounds of one workgroup per CU, each walking n / ns rows, plus the slab traffic that grows with ns (K Mp^2
+  // floats written and read per split: 0.13 ms at 64 splits, M = 512, K = 10 - a fixed cost that does not shrink with a rank's share
+  // of the rows; at the 8-GPU per-rank size of the headline workload the optimum moves from 64 to ~25 splits)
+  const double chunk_us = 3.7;                                   // one 32-row chunk of a (tile, topic group) unit: 9.0 ms at N = 1e6, M = 512, K = 10
+  const double slab_us_per_split = 2.0 * (double)c->K * c->Mp * c->Mp * 4.0 / 5.0e6;       // bytes at ~5 TB/s, in us
+  int best = 1; double best_t = 1e300;
   for (int ns = 1; ns <= maxs; ++ns) {
-    const double rounds = units * (double)ns / 256.0;
-    const double eff = rounds / std::ceil(rounds);
-    if (eff > best_eff + 0.01) { best_eff = eff; best = ns; }
+    const double rounds = std::ceil(units * (double)ns / 256.0);
+    const double t = rounds * std::ceil((double)n / (32.0 * ns)) * chunk_us + ns * slab_us_per_split;
+    if (t < best_t * 0.995) { best_t = t; best = ns; }
   }
   return best;
 }

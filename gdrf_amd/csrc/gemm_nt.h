@@ -50,6 +50,13 @@ template <typename T> struct NTCfg {
 template <typename T> __device__ __forceinline__ int nt_stage_row(int i) { return (int)(threadIdx.x / NTCfg<T>::VPR) + (256 / NTCfg<T>::VPR) * i; }
 template <typename T> __device__ __forceinline__ int nt_stage_k() { return (int)(threadIdx.x % NTCfg<T>::VPR) * NTCfg<T>::VE; }
 
+// triangular reductions at MFMA-tile granularity (a problem may declare `static constexpr int TRI`): krange() cuts the reduction at the
+// granularity of a column tile (64 or 128 columns), so the chunks that cross the diagonal block multiply zeros for part of the 16-column
+// MFMA tiles.  TRI = 1 (Bt[col][k] = 0 for k > col, the forward solve): a chunk starting at k is needed by the 16 columns from c0 only if
+// k <= c0 + 15;  TRI = 2 (Bt[col][k] = 0 for k < col, the backward solve): only if k + BK - 1 >= c0.  The test is wave-uniform.
+template <class P, class = void> struct NTTri { static constexpr int value = 0; };
+template <class P> struct NTTri<P, decltype((void)P::TRI)> { static constexpr int value = P::TRI; };
+
 // workgroups per CU the register allocation must leave room for (a problem may declare `static constexpr int MIN_WGS`)
 template <class P, class = void> struct NTMinWgs { static constexpr int value = 2; };
 template <class P> struct NTMinWgs<P, decltype((void)P::MIN_WGS)> { static constexpr int value = P::MIN_WGS; };
@@ -77,6 +84,7 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+  const int wc_u = __builtin_amdgcn_readfirstlane(wc);
   const int nct = p.col_tiles();
   const bool loopc = p.loop_cols();
   int64_t rtile; int ct_first;
@@ -125,8 +133,14 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
       for (int i = 0; i < C::VPTB; ++i) rb[i] = p.loadB(n0, i, kA + srow_k, rep, bz);
     };
     // multiply the staged chunk out of LDS (rep < 0: no per-row scale)
-    auto compute = [&](int rep) {
+    auto compute = [&](int rep, int kA = 0) {
       T sc[4];
+      bool need[C::NB];
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) {
+        const int c0 = n0 + wc_u * (C::CW / 2) + b * 16;
+        need[b] = NTTri<P>::value == 1 ? (kA <= c0 + 15) : (NTTri<P>::value == 2 ? (kA + C::BK - 1 >= c0) : true);
+      }
       if (P::SCALE_A) {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) sc[t4] = rep >= 0 ? scaleS[rep * GDRF_TILE + wr * 64 + t4 * 16 + lr] : T(1);
@@ -152,7 +166,9 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < C::NB; ++b) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
+            for (int b = 0; b < C::NB; ++b) {
+              if (NTTri<P>::value == 0 || need[b]) acc[a][b] = MM::mma(fa[a][e], fb[b][e], acc[a][b]);
+            }
       }
     };
     auto body = [&](typename P::AVec (&ra)[C::VPT], V (&rb)[C::VPTB], int c) {
@@ -167,7 +183,7 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
       for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
       __syncthreads();
       if (c + P::DEPTH < nchunks) gload(ra, rb, c + P::DEPTH);      // refill the set just consumed
-      compute(rep);
+      compute(rep, kA);
     };
     if (P::DEPTH == 1) {
       if (nchunks > 0) gload(ra0, rb0, 0);

@@ -124,32 +124,44 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
     }
   };
   // split x (4 columns of this lane's row) for the topic pair pr of chunk c into B image (buffer q, slot sl)
+  // Two neighbouring elements (xa, xb) times the row factor v -> packed fp16 pairs H = (h_a, h_b) and L = (l'_a, l'_b), l' = 2^11 (x v - h):
+  // six mixed-precision FMAs - h = f16(x v) from the exact product (v_fma_mixlo/hi_f16 write one half each), the residual x v - h exactly
+  // in f32 (v_fma_mix_f32 with the fp16 half as its third operand), l' = f16(2048 r).  Written as asm because (a) hipcc's own code for
+  // the scalar formulation is ~14 instructions per pair (multiply, convert, convert back, subtract, multiply, convert, byte permutes) -
+  // this is the vector work the kernel's phases wait for - and (b) its SLP-vectorized form of it produced run-to-run different results
+  // (packed-f32 code with op_sel; ROCm 7.2).  The trailing s_nop pads the VALU write -> LDS store-data read that follows in compiler code.
+  const float c2048 = 2048.0f;
+  auto split2 = [&](float xa, float xb, float v, unsigned& H, unsigned& L) {
+    float ra, rb2;
+    asm("v_fma_mixlo_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %4, 0\n\t"
+        "v_fma_mix_f32 %1, %3, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %2, %5, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(H), "=&v"(ra), "=&v"(rb2) : "v"(xa), "v"(v), "v"(xb));
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0\n\t"
+        "s_nop 1"
+        : "=&v"(L) : "v"(ra), "v"(rb2), "v"(c2048));
+  };
+  // split x (4 columns of this lane's row) for the topic pair pr of chunk c into B image (buffer q, slot sl)
   auto split_pair = [&](const f32x4& x, int c, int pr, int q, int sl) {
     const float* vt = vtab + ((c & 1) * KT + 2 * pr) * 32 + brow;
     const float okf = b_ok ? 1.0f : 0.0f;
     const float v0 = vt[0] * okf, v1 = vt[32] * okf;                      // 2 pr + 1 < KT always (KT even); unconditional LDS reads
-    V4 pv[2][NP];
+    unsigned hw[2][NP][2];                                                 // [topic of the pair][piece][element pair]
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      E p0[NP], p1[NP];
-      // The values pass through empty asm statements so that hipcc's SLP vectorizer leaves this arithmetic scalar: the packed-f32 code
-      // (v_pk_mul_f32 / v_pk_fma_f32 with op_sel) it made of the four elements x two topics produced run-to-run different results
-      // with non-finite low pieces for the second topic of the slot split during phase 0 (ROCm 7.2; -fno-slp-vectorize for the whole
-      // library cures it too but costs bwd_wbar its packed accumulator updates: 48.1 -> 49.0 ms per step)
-      float y0 = x[e] * v0, y1 = x[e] * v1;
-      asm volatile("" : "+v"(y0), "+v"(y1));
-      p0[0] = (E)y0; p1[0] = (E)y1;
-      float r0 = y0 - (float)p0[0], r1 = y1 - (float)p1[0];
-      asm volatile("" : "+v"(r0), "+v"(r1));
-      p0[1] = (E)(r0 * 2048.0f); p1[1] = (E)(r1 * 2048.0f);               // l' = 2^11 l (see the header comment)
-#pragma unroll
-      for (int s = 0; s < NP; ++s) { pv[0][s][e] = p0[s]; pv[1][s][e] = p1[s]; }
+    for (int h2 = 0; h2 < 2; ++h2) {
+      split2(x[2 * h2], x[2 * h2 + 1], v0, hw[0][0][h2], hw[0][1][h2]);
+      split2(x[2 * h2], x[2 * h2 + 1], v1, hw[1][0][h2], hw[1][1][h2]);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int so = tnb_seg(brow, bc4 + 16 * t) * 4;
 #pragma unroll
-      for (int s = 0; s < NP; ++s) *reinterpret_cast<V4*>(Bs + ((q * PPH + sl) * NP + s) * PIECE + so) = pv[t][s];
+      for (int s = 0; s < NP; ++s) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(Bs + ((q * PPH + sl) * NP + s) * PIECE + so) = u32x2{hw[t][s][0], hw[t][s][1]};
+      }
     }
   };
   // fragments (geometry of gemm_tn_split_kernel): two transposing reads of 4 rows x 16 columns each

@@ -241,6 +241,9 @@ template <typename T, typename TN, bool DERIV = false, int DD = 2> struct FwdWPr
   static constexpr bool A_PER_REP = false;
   static constexpr int DEPTH = 1;
   static constexpr int MIN_WGS = (sizeof(T) == 8 && !DERIV) ? GDRF_FWDW_WGS : 2;
+#ifndef GDRF_NO_TRI
+  static constexpr int TRI = 1;            // W[n][col] = sum_{k <= col} K_nm[n][k] Linv[col][k]
+#endif
   const T* Knm; int64_t nrows; int Mp;
   const T* Linv; TN* W; TN* qpart; int64_t ldq;      // qpart [col_tiles][ldq]
   const TN* X = nullptr; const T* Z = nullptr; const Hyper* h = nullptr; int M = 0, D = 0, kind = 0;   // DERIV only
@@ -722,6 +725,9 @@ template <typename T> struct BwdWbarTProb : NTXcdPairMap, NTPlainA<T> {
 template <typename T, typename TN, bool LZ = false> struct BwdKnmProb : NTXcdRowMap, NTNoExtra {
   using V = typename Vec16<T>::type;
   static constexpr int MIN_WGS = (sizeof(T) == 8 && !LZ) ? 3 : 2;   // f64: three workgroups per CU hide each other's epilogues
+#ifndef GDRF_NO_TRI
+  static constexpr int TRI = 2;            // Kbar[n][col] = sum_{k >= col} Wbar[n][k] LinvT[col][k]
+#endif
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
   static constexpr int DEPTH = 1;
