@@ -13,6 +13,9 @@
 #define GDRF_KBYTES_F64 0      // the same for f64 operands (0: GDRF_KBYTES).  256 (32 doubles per chunk, half the barriers per MFMA) was
                                // measured SLOWER: 180 registers -> 2 workgroups per CU, fwd_w 6.55 -> 7.03 ms
 #endif
+#ifndef GDRF_FWDW_DEPTH
+#define GDRF_FWDW_DEPTH 2        // register prefetch distance (chunks) of the f64 W = K_nm L^-T kernel
+#endif
 #define GDRF_MPAD 32           // M is padded to a multiple of this in every workspace matrix
 #define GDRF_DMAX 4            // input dimensions supported (index columns of the reference's CSV)
 

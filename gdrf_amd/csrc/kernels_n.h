@@ -239,7 +239,7 @@ template <typename T, typename TN, bool DERIV = false, int DD = 2> struct FwdWPr
   using AVec = V;
   static constexpr bool SCALE_A = false;
   static constexpr bool A_PER_REP = false;
-  static constexpr int DEPTH = 1;
+  static constexpr int DEPTH = (sizeof(T) == 8 && !DERIV) ? GDRF_FWDW_DEPTH : 1;
   static constexpr int MIN_WGS = (sizeof(T) == 8 && !DERIV) ? GDRF_FWDW_WGS : 2;
 #ifndef GDRF_NO_TRI
   static constexpr int TRI = 1;            // W[n][col] = sum_{k <= col} K_nm[n][k] Linv[col][k]
