@@ -32,6 +32,8 @@ SIGNATURES = {
     "gdrf_red_layout": (_int, [_vp, C.POINTER(_i64)]),
     "gdrf_payload_pack": (_int, [_vp, _vp, _vp, _vp]),
     "gdrf_payload_unpack": (_int, [_vp, _vp, _vp, _vp]),
+    "gdrf_set_allreduce": (_int, [_vp, _vp, _vp]),
+    "gdrf_payload_allreduce": (_int, [_vp, _vp, _vp, _vp]),
     "gdrf_set_dirichlet": (_int, [_vp, C.POINTER(_dbl)]),
     "gdrf_knm": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gdrf_fill_eps": (_int, [_vp, C.c_uint64, C.c_uint32, _i64, _i64, _vp, _vp]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     "gdrf_set_timing": (_int, [_vp, _int]),
     "gdrf_get_timing": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64), _int]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(_int, _vp, _i64, _int, _vp, _vp)       # gdrf_allreduce_fn of include/gdrf_hip.h
 
 _lib = None
 

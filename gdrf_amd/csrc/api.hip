@@ -64,6 +64,7 @@ struct gdrf_ctx {
   void *Wd;                   // W' = (dK_nm / d log lengthscale) Linv^T, allocated on first use (fixed inducing inputs, kernels without a third hyper-parameter)
   double* wdpart; hipEvent_t ev_wd;
   void* dKh; hipStream_t side2; hipEvent_t ev_ak, ev_ak_done;    // pieces of dK_nm / d log ls (hyper_tn.h), allocated on first use; third stream: A_k beside the f64 backward GEMM
+  gdrf_allreduce_fn allreduce; void* allreduce_user;      // the caller's collective (gdrf_set_allreduce), or null
   int hyper_tn; double* hpart;   // K_nm parts of the hyper-parameter gradients through Hd = dK^T Wbar on the TN kernel (hyper_tn.h) instead of the f64 backward GEMM
   void *Bh, *STh, *Wh;        // 16-bit pieces of B_k, S_k^T and W (f32 contexts; split-operand MFMA forms, gemm_split.h)
   int split;                  // 0: native f32 MFMA; 1: "bf16x6" (3 bf16 pieces, 6 products); 2: "f16x3" (2 fp16 pieces, 3 products, block scales)
@@ -242,7 +243,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   c->lgam_const = 0; c->alpha_dev = nullptr; c->timing = 0;
   c->pK = c->pL = nullptr; c->Tst = nullptr; c->side = nullptr; c->Bh = c->STh = c->Wh = nullptr; c->split = 0; c->wh_pieces = 0; c->ssc = nullptr; c->smx = nullptr;
   c->ev_fork = c->ev_loc = c->ev_fork2 = c->ev_join = c->ev_fact0 = c->ev_fact = nullptr; c->fact_pending = 0; c->learn_z = 0; c->zpart = nullptr; c->unwhitened = 0; c->mean = nullptr; c->mean_sk = c->mean_sn = 0;
-  c->hyper_tn = 0; c->hpart = nullptr; c->dKh = nullptr; c->side2 = nullptr; c->ev_ak = c->ev_ak_done = nullptr; c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr; c->g_loc = nullptr; c->mean_g = nullptr; c->mean_g_sk = c->mean_g_sn = 0;
+  c->allreduce = nullptr; c->allreduce_user = nullptr; c->hyper_tn = 0; c->hpart = nullptr; c->dKh = nullptr; c->side2 = nullptr; c->ev_ak = c->ev_ak_done = nullptr; c->uS = c->uSb = c->uSc = c->uU = c->uUb = c->Uw = nullptr; c->Wd = nullptr; c->wdpart = nullptr; c->ev_wd = nullptr; c->g_loc = nullptr; c->mean_g = nullptr; c->mean_g_sk = c->mean_g_sn = 0;
   for (int i = 0; i < GDRF_NSLOTS; ++i) { c->t_ms[i] = 0; c->t_cnt[i] = 0; }
   const size_t mm = (size_t)c->Mp * c->Mp * c->esz, mms = (size_t)c->Mp * c->Mp * c->ssz;
   auto A = [&](void** p, size_t bytes) -> int {
@@ -1496,6 +1497,19 @@ int gdrf_payload_unpack(gdrf_ctx* c, const void* redT, double* redd, void* strea
   else hipLaunchKernelGGL(payload_unpack_kernel<float>, dim3((nd + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)redT + roff(c, 5), nd, redd);
   LAUNCHCHK("payload_unpack");
   return 0;
+}
+
+int gdrf_set_allreduce(gdrf_ctx* c, gdrf_allreduce_fn fn, void* user) {
+  c->allreduce = fn; c->allreduce_user = user;
+  return 0;
+}
+// the step's single collective: pack red_d into the tail of red_T, the caller's sum over the ranks on the whole flat buffer, unpack
+int gdrf_payload_allreduce(gdrf_ctx* c, void* redT, double* redd, void* stream) {
+  if (!c->allreduce) return 0;
+  if (int rc = gdrf_payload_pack(c, redT, redd, stream)) return rc;
+  const int rc = c->allreduce(redT, roff(c, 4), c->esz == 8 ? 1 : 0, stream, c->allreduce_user);
+  if (rc) return fail(-2, "gdrf_payload_allreduce", "the registered all-reduce function reported an error");
+  return gdrf_payload_unpack(c, redT, redd, stream);
 }
 
 int gdrf_ll_const_dev(gdrf_ctx* c, const int32_t* ws, int64_t n, double* out_dev, void* stream) {

@@ -35,7 +35,7 @@ class Engine:
     def __init__(self, n_cap: int, M: int, K: int, V: int, D: int, *, dtype=torch.float32, kernel: str = "rbf",
                  device="cuda:0", jitter: float = 1e-8, maxjitter: int = 15, process_group="auto", pure_fp32: bool = False,
                  store_t="auto", mfma_mode: str = "auto", learn_inducing: bool = False, whiten: bool = True,
-                 hyper_backward: str = "auto"):
+                 hyper_backward: str = "auto", allreduce_fn=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GdrfHipError("gdrf_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -77,6 +77,11 @@ class Engine:
             raise ValueError("hyper_backward must be 'auto', 'tn' or 'f64'")
         _lib.check(self.lib.gdrf_set_hyper_backward(self.ctx, 1 if hyper_backward == "tn" else 0), "gdrf_set_hyper_backward")
         self._hyper_backward_request = hyper_backward
+        # a caller-owned collective behind the C ABI (gdrf_set_allreduce): fn(buf_ptr, count, is_double, stream_ptr) -> 0 sums the flat payload in
+        # place over the caller's ranks (e.g. a ctypes wrapper of ncclAllReduce on its RCCL communicator); None = torch.distributed (default)
+        self._allreduce_cb = None
+        if allreduce_fn is not None:
+            self.set_allreduce(allreduce_fn)
         lay = (C.c_int64 * 7)()
         _lib.check(self.lib.gdrf_param_layout(self.ctx, lay), "gdrf_param_layout")
         zl = (C.c_int64 * 2)()
@@ -112,6 +117,22 @@ class Engine:
         # a caller-supplied link (the reference's `link_function`, abstract_gdrf.py:34-50): a callable on the (K, n) tensor mu returning the
         # (K, n) topic weights; None = the softmax link fused into the row kernel.  Evaluated with torch between three library calls.
         self.link_function = None
+
+    def set_allreduce(self, fn):
+        """Register the step's collective behind the C ABI (gdrf_set_allreduce): ``fn(buf_ptr, count, is_double, stream_ptr)`` sums the flat
+        payload in place over the caller's ranks and returns 0 / None; None unregisters (back to torch.distributed, or one rank)."""
+        if fn is None:
+            self._allreduce_cb = None
+            _lib.check(self.lib.gdrf_set_allreduce(self.ctx, None, None), "gdrf_set_allreduce")
+            return
+
+        def _cb(buf, count, is_double, stream, user, _fn=fn):
+            try:
+                return int(_fn(buf, count, bool(is_double), stream) or 0)
+            except Exception:
+                return 1
+        self._allreduce_cb = _lib.ALLREDUCE_FN(_cb)              # kept alive with the engine
+        _lib.check(self.lib.gdrf_set_allreduce(self.ctx, C.cast(self._allreduce_cb, C.c_void_p), None), "gdrf_set_allreduce")
 
     @property
     def hyper_backward(self) -> str:
@@ -414,8 +435,13 @@ class Engine:
                 _lib.check(self.lib.gdrf_step_local2(self.ctx, xs.data_ptr(), xg.data_ptr(), ws.data_ptr(), eps[p].data_ptr(), n,
                                                      self.Z.data_ptr(), self.params.data_ptr(), self.red_T.data_ptr(),
                                                      self.red_d.data_ptr(), s), "gdrf_step_local2")
-            if P > 1 or renyi_alpha is not None:
+            if renyi_alpha is not None:
                 Ts.append(self.red_T.clone()); ds.append(self.red_d.clone())
+            elif P > 1:                                           # Trace_ELBO: a running sum of the payloads, no per-particle copies
+                if p == 0:
+                    accT, accd = self.red_T.clone(), self.red_d.clone()
+                else:
+                    accT.add_(self.red_T); accd.add_(self.red_d)
         if renyi_alpha is not None:
             T_all, d_all = torch.stack(Ts), torch.stack(ds)
             e = d_all[:, 0] + d_all[:, 1]                         # this rank's site + likelihood sums per particle
@@ -431,10 +457,12 @@ class Engine:
             self.red_d[0] = bound * ng if first else 0.0
             self.red_d[1] = 0.0
         elif P > 1:
-            self.red_T.copy_(torch.stack(Ts).mean(0))
-            self.red_d.copy_(torch.stack(ds).mean(0))
+            self.red_T.copy_(accT.div_(P))
+            self.red_d.copy_(accd.div_(P))
         self.red_d[7:8].copy_(llc)                   # the data constant is a sum over observations too; stays on the device
-        if dist_on:
+        if self._allreduce_cb is not None:           # the caller's collective, behind the C ABI (pack, its sum over the ranks, unpack)
+            _lib.check(self.lib.gdrf_payload_allreduce(self.ctx, self.red_T.data_ptr(), self.red_d.data_ptr(), s), "gdrf_payload_allreduce")
+        elif dist_on:
             # ONE collective per step: the doubles of red_d ride in the tail of the flat payload (exactly in float64 contexts; as four
             # float pieces each in float32 ones: exact over <= 8 ranks for the loss sums, whose per-rank values have similar magnitude,
             # and to 2^-24 of the largest summand for entries that differ by orders of magnitude between ranks - csrc/kernels_n.h)

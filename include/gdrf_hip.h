@@ -108,6 +108,15 @@ int gdrf_red_layout(const gdrf_ctx* ctx, int64_t out[6]);
  * for float ones -; the caller all-reduces red_T alone and gdrf_payload_unpack restores red_d from the reduced tail. */
 int gdrf_payload_pack(gdrf_ctx* ctx, void* red_T_dev, const double* red_d_dev, void* stream);
 int gdrf_payload_unpack(gdrf_ctx* ctx, const void* red_T_dev, double* red_d_dev, void* stream);
+/* The collective behind the C ABI, for hosts that do not go through torch.distributed: the caller registers ONE function that sums
+ * `count` elements of `buf` (device memory; float when is_double = 0, double otherwise) in place over its ranks on `stream` - e.g. a
+ * wrapper of ncclAllReduce(buf, buf, count, ncclFloat / ncclDouble, ncclSum, comm, stream) on the RCCL communicator it owns (`user`) - and
+ * returns 0 on success.  gdrf_payload_allreduce then is the step's single collective: pack, that function on the whole flat payload
+ * (total_T elements of gdrf_red_layout), unpack.  With no function registered it is a no-op (one rank).  gdrf_amd.Engine uses it when it is
+ * constructed with allreduce_fn=...; its default remains torch.distributed.all_reduce between gdrf_payload_pack and gdrf_payload_unpack. */
+typedef int (*gdrf_allreduce_fn)(void* buf_dev, int64_t count, int is_double, void* stream, void* user);
+int gdrf_set_allreduce(gdrf_ctx* ctx, gdrf_allreduce_fn fn, void* user);
+int gdrf_payload_allreduce(gdrf_ctx* ctx, void* red_T_dev, double* red_d_dev, void* stream);
 /* Dirichlet concentration (K*V doubles, host): validate_dirichlet_param, gdrf/models/utils.py:6-24. */
 int gdrf_set_dirichlet(gdrf_ctx* ctx, const double* alpha_host);
 

@@ -110,15 +110,28 @@ def _dist_worker(rank, world, port, tmp):
     N = len(xs)
     lo, hi = rank * N // world, (rank + 1) * N // world
     svi.row_offset = lo
+    if os.environ.get("GDRF_TEST_C_ABI_ALLREDUCE") == "1":
+        # the collective registered behind the C ABI (gdrf_set_allreduce / gdrf_payload_allreduce) instead of the engine's own
+        # torch.distributed call: what a non-Python host would do with ncclAllReduce on its RCCL communicator
+        eng = model._engine_for(hi - lo)
+        eng.pg = None
+
+        def allreduce(buf, count, is_double, stream):
+            assert buf == eng.red_T.data_ptr() and count == eng.red_T.numel() and is_double == (eng.dtype == torch.float64)
+            dist.all_reduce(eng.red_T)
+            return 0
+        eng.set_allreduce(allreduce)
     losses = [svi.step(xs=xs[lo:hi], ws=ws[lo:hi], subsample=False) for _ in range(3)]
     torch.save({"losses": losses, "params": model._engine.params.cpu()}, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
+@pytest.mark.parametrize("via", ["torch_distributed", "c_abi_hook"])
+def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path, via, monkeypatch):
     import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() % 2000)
+    monkeypatch.setenv("GDRF_TEST_C_ABI_ALLREDUCE", "1" if via == "c_abi_hook" else "0")
+    port = 29600 + (os.getpid() % 2000) + (7 if via == "c_abi_hook" else 0)
     mp.spawn(_dist_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     model, svi, _, xs, ws = _build(dtype=torch.float64)
     ref = [svi.step(xs=xs, ws=ws, subsample=False) for _ in range(3)]
