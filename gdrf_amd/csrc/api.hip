@@ -926,7 +926,26 @@ template <typename T, typename TS> struct Impl {
       if (c->split && sizeof(TS) == 8 && sizeof(T) == 4) {      // pieces of W from the same epilogue
         p.Wh = c->Wh; p.wh_stride = (int64_t)c->ncap * Mp; p.wh_mode = c->split; p.wh_scale = c->ssc + SplitLay{K}.w();
       }
+#ifdef GDRF_NT_TRACE   // diagnostic builds only: per-workgroup phase stamps of this launch written to $GDRF_NT_TRACE_FILE (tools/nt_trace.py)
+      unsigned long long* trace_d = nullptr; const size_t trace_n = (size_t)nt_xcd_row_grid(rtiles, nct<TS>(c)) * 8;
+      if (getenv("GDRF_NT_TRACE_FILE") && sizeof(TS) == 8) {
+        HIPCHK(hipMalloc((void**)&trace_d, trace_n * 8)); HIPCHK(hipMemset(trace_d, 0, trace_n * 8));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nt_trace), &trace_d, sizeof(trace_d)));
+        HIPCHK(hipDeviceSynchronize());
+      }
+#endif
       hipLaunchKernelGGL((gemm_nt_kernel<TS, FwdWProb<TS, T>>), dim3(nt_xcd_row_grid(rtiles, nct<TS>(c))), dim3(256), CS::LDS_BYTES, s, p);
+#ifdef GDRF_NT_TRACE
+      if (trace_d) {
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(trace_n);
+        HIPCHK(hipMemcpy(h.data(), trace_d, trace_n * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("GDRF_NT_TRACE_FILE"), "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+        unsigned long long* z = nullptr;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nt_trace), &z, sizeof(z)));
+        (void)hipFree(trace_d);
+      }
+#endif
     }
     // loc = W U^T, on the side stream beside fwd_t (both only read W)
     HIPCHK(hipEventRecord(c->ev_fork, s));

@@ -63,6 +63,15 @@ template <class P> struct NTMinWgs<P, decltype((void)P::MIN_WGS)> { static const
 
 template <typename T, class P> __device__ __forceinline__ void gemm_nt_body(P& p);
 
+#ifdef GDRF_NT_TRACE   // diagnostic builds only: per-workgroup phase stamps of the problems that declare TRACE (tools/nt_trace.py)
+__device__ unsigned long long* g_nt_trace = nullptr;       // [workgroup][8]: block | column tile << 32, hw id, xcc id, t start, t first chunk staged, t loop end, t tile end, t end
+template <class P, class = void> struct NTTrace { static constexpr bool value = false; };
+template <class P> struct NTTrace<P, decltype((void)P::TRACE)> { static constexpr bool value = P::TRACE; };
+#define NT_STAMP(slot) do { if (NTTrace<P>::value && g_nt_trace && threadIdx.x == 0 && blockIdx.y == 0) g_nt_trace[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define NT_STAMP(slot) do {} while (0)
+#endif
+
 template <typename T, class P>
 __global__ __launch_bounds__(256, NTMinWgs<P>::value) void gemm_nt_kernel(P p) { gemm_nt_body<T, P>(p); }
 
@@ -94,6 +103,14 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
   const int bz = p.batch_index(blockIdx.x, blockIdx.y);
   const int R = p.a_reuse();
 
+#ifdef GDRF_NT_TRACE
+  if (NTTrace<P>::value && g_nt_trace && threadIdx.x == 0 && blockIdx.y == 0) {
+    g_nt_trace[(size_t)blockIdx.x * 8 + 0] = blockIdx.x | ((unsigned long long)ct_first << 32);
+    g_nt_trace[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave, SIMD, CU, SH, SE
+    g_nt_trace[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+  }
+  NT_STAMP(3);
+#endif
   typename P::ACtx actx;
   p.prepA(actx, m0, bz, extra);
   typename P::ECtx ectx;
@@ -182,6 +199,7 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
 #pragma unroll
       for (int i = 0; i < C::VPTB; ++i) *reinterpret_cast<V*>(&Bs[nt_stage_row<T>(i) * C::LDK + srow_k]) = rb[i];
       __syncthreads();
+      if (c == 0) NT_STAMP(4);
       if (c + P::DEPTH < nchunks) gload(ra, rb, c + P::DEPTH);      // refill the set just consumed
       compute(rep, kA);
     };
@@ -204,9 +222,12 @@ __device__ __forceinline__ void gemm_nt_body(P& p) {
       __syncthreads();
       compute(-1);
     }
+    NT_STAMP(5);
     p.tile_done(acc, m0, n0, bz, ectx, wr, wc, lane);
+    NT_STAMP(6);
   }
   p.finish(m0, bz, ectx, smem, wr, wc, lane);
+  NT_STAMP(7);
 }
 
 // element (row, col) of accumulator register r of MFMA tile (a, b) inside the workgroup tile
@@ -252,6 +273,15 @@ struct NTXcdMap {
 // XCD-aware map that keeps ALL column tiles of a row tile on one XCD, dispatched back to back: their A operand (the
 // row tile's slab, cold in HBM) is then fetched once into that XCD's L2 and shared, instead of once per column tile.
 // Grid: nt_xcd_row_grid(rtiles, nct); padding blocks get rtile >= rtiles.
+//
+// The ORDER of the column tiles inside an XCD's sequence matters for triangular reductions (column tile ct costing ct + 1 or nct - ct
+// units).  Measured with per-workgroup stamps (tools/nt_trace.py, profiles/r03/README.md): workgroup b of a launch runs on XCD b mod 8
+// and, inside it, on shader engine (b / 8) mod 4 - a STATIC round robin - and workgroups are placed in order, so the engine that is
+// handed the most work is always full (24 workgroups on its 8 CUs) while the launch waits for it and the three others starve.  In
+// plain order (ct = 0, 1, 2, ...) engine e of every XCD only ever sees the column tiles ct = e mod 4 - 6 : 8 : 10 : 12 units - and
+// the f64 solve GEMMs held 1.87 of the 3 workgroups per CU their registers allow.  The tiles are therefore dealt in a serpentine over
+// groups of four (0 1 2 3 | 7 6 5 4 | 8 9 10 11 | 15 ...), the group counter running on across row tiles: every engine then sees
+// ct and its mirror in turn and carries the same work.
 inline unsigned nt_xcd_row_grid(int64_t rtiles, int nct) { return (unsigned)(8 * nct * ((rtiles + 7) / 8)); }
 struct NTXcdRowMap {
   __device__ __forceinline__ int batch_index(unsigned, unsigned by) const { return (int)by; }
@@ -260,6 +290,9 @@ struct NTXcdRowMap {
     const unsigned xcd = bid & 7u, idx = bid >> 3;
     rtile = (int64_t)(idx / (unsigned)nct) * 8 + xcd;
     ct = (int)(idx % (unsigned)nct);
+#ifndef GDRF_NT_PLAIN_ORDER
+    if ((nct & 3) == 0 && ((idx >> 2) & 1u)) ct = (ct & ~3) + 3 - (ct & 3);      // odd group of four: reversed (idx / 4 counts groups across row tiles)
+#endif
   }
 };
 
@@ -276,8 +309,8 @@ struct NTXcdRowBatchMap {
 };
 
 // XCD-aware map for TRIANGULAR reductions, where column tile ct costs (ct+1) units: column tiles are paired
-// (ct, nct-1-ct) so that every XCD alternates a light and a heavy tile (equal work per XCD) while still keeping
-// only two tiles' B panels in its L2.  The XCDs that share a pair deal the row tiles round-robin.
+// (ct, nct-1-ct) so that every XCD alternates a light and a heavy tile (equal work per XCD and, with the order flipped every
+// four workgroups, per shader engine) while still keeping only two tiles' B panels in its L2.  The XCDs that share a pair deal the row tiles round-robin.
 // Grid: nt_xcd_pair_grid(rtiles, nct).  Falls back to the default order when nct is odd or does not divide 8.
 __host__ __device__ inline bool nt_xcd_pair_ok(int nct) { return nct >= 2 && nct <= 8 && (nct % 2) == 0 && (8 % nct) == 0; }
 inline unsigned nt_xcd_pair_grid(int64_t rtiles, int nct) {
@@ -295,7 +328,7 @@ struct NTXcdPairMap {
     const int pid = c < half ? c : nct - 1 - c;
     const int r = (int)(xcd / (unsigned)nct) * 2 + (c >= half ? 1 : 0);
     rtile = (int64_t)(idx >> 1) * nper + r;
-    ct = (idx & 1u) ? nct - 1 - pid : pid;
+    ct = ((idx ^ (idx >> 2)) & 1u) ? nct - 1 - pid : pid;   // light, heavy, light, heavy | heavy, light, ...: the shader engine is (idx mod 4), see NTXcdRowMap
   }
 };
 

@@ -145,6 +145,9 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
   };
   // split x (4 columns of this lane's row) for the topic pair pr of chunk c into B image (buffer q, slot sl)
   auto split_pair = [&](const f32x4& x, int c, int pr, int q, int sl) {
+#if defined(GDRF_DIAG) && GDRF_AK_ABLATE == 1      // timing-only: no split / image writes after the first chunk (wrong results)
+    if (c > 0) return;
+#endif
     const float* vt = vtab + ((c & 1) * KT + 2 * pr) * 32 + brow;
     const float okf = b_ok ? 1.0f : 0.0f;
     const float v0 = vt[0] * okf, v1 = vt[32] * okf;                      // 2 pr + 1 < KT always (KT even); unconditional LDS reads
@@ -190,6 +193,9 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
     for (int sl = 0; sl < PPH; ++sl) if (sl < npair) split_pair(rb, 0, sl, 0, sl);
     phase_barrier();
     int q = 0;
+#if defined(GDRF_DIAG) && GDRF_AK_ABLATE == 2
+    V8 fbk[2][NP];
+#endif
     V8 fa[2][NP], fa2[2];                    // fa2 = 2^-11 x the high piece: partner of the B operand's up-scaled low piece
     for (int c = 0; c < nch; ++c) {
       f32x4 rbn = rb;
@@ -227,10 +233,35 @@ __global__ __launch_bounds__(512, 2) void tn_topics_f16_kernel(TNTopicsArgs g) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                   V8 fb[2][NP];
+#if defined(GDRF_DIAG) && GDRF_AK_ABLATE == 2      // timing-only: one B fragment set per phase instead of one per topic (wrong results)
+                  if (sl == 0 && t == 0) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                      for (int s = 0; s < NP; ++s) fb[b][s] = frag(Bs + ((q * PPH + sl) * NP + s) * PIECE, 4 * t + 2 * wj + b);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                      for (int s = 0; s < NP; ++s) fbk[b][s] = fb[b][s];
+                  } else {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                      for (int s = 0; s < NP; ++s) fb[b][s] = fbk[b][s];
+                  }
+#else
 #pragma unroll
                   for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int s = 0; s < NP; ++s) fb[b][s] = frag(Bs + ((q * PPH + sl) * NP + s) * PIECE, 4 * t + 2 * wj + b);
+#endif
+#if defined(GDRF_DIAG) && GDRF_AK_ABLATE == 3      // timing-only: no MFMA (wrong results)
+#pragma unroll
+                  for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int s = 0; s < NP; ++s) asm volatile("" :: "v"(fb[b][s]));
+                  continue;
+#endif
 #pragma unroll
                   for (int x = 0; x < SP::NPROD; ++x)
 #pragma unroll

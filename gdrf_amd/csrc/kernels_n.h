@@ -241,6 +241,9 @@ template <typename T, typename TN, bool DERIV = false, int DD = 2> struct FwdWPr
   static constexpr bool A_PER_REP = false;
   static constexpr int DEPTH = (sizeof(T) == 8 && !DERIV) ? GDRF_FWDW_DEPTH : 1;
   static constexpr int MIN_WGS = (sizeof(T) == 8 && !DERIV) ? GDRF_FWDW_WGS : 2;
+#ifdef GDRF_NT_TRACE
+  static constexpr bool TRACE = sizeof(T) == 8 && !DERIV;
+#endif
 #ifndef GDRF_NO_TRI
   static constexpr int TRI = 1;            // W[n][col] = sum_{k <= col} K_nm[n][k] Linv[col][k]
 #endif
