@@ -5,6 +5,7 @@
 #include "gemm_tn.h"
 #include "gemm_split.h"
 #include "gemm_tn_topics.h"
+#include "gemm_tn_topics1.h"
 #include "kernels_mm.h"
 #include "kernels_n.h"
 #include "predict.h"
@@ -66,6 +67,7 @@ struct gdrf_ctx {
   void* dKh; hipStream_t side2; hipEvent_t ev_ak, ev_ak_done;    // pieces of dK_nm / d log ls (hyper_tn.h), allocated on first use; third stream: A_k beside the f64 backward GEMM
   gdrf_allreduce_fn allreduce; void* allreduce_user;      // the caller's collective (gdrf_set_allreduce), or null
   int hyper_tn; double* hpart;   // K_nm parts of the hyper-parameter gradients through Hd = dK^T Wbar on the TN kernel (hyper_tn.h) instead of the f64 backward GEMM
+  void* vbs = nullptr;        // vbar x block scale, zero-padded to a multiple of 64 rows (gemm_tn_topics1.h)
   void *Bh, *STh, *Wh;        // 16-bit pieces of B_k, S_k^T and W (f32 contexts; split-operand MFMA forms, gemm_split.h)
   int split;                  // 0: native f32 MFMA; 1: "bf16x6" (3 bf16 pieces, 6 products); 2: "f16x3" (2 fp16 pieces, 3 products, block scales)
   int wh_pieces;              // pieces Wh has room for
@@ -266,6 +268,7 @@ int gdrf_ctx_create_ex(gdrf_ctx** out, int device, int64_t n_cap, int M, int K, 
   AL(c->pK, mm) AL(c->pL, mm * 8)          // probe scratch: K_uu without jitter, 8 level copies
   AL(c->S, mm * K) AL(c->ST, mm * K) AL(c->Bm, mm * K) AL(c->Sbar, mm * K)
   if (c->esz == 4) { AL(c->Bh, (size_t)3 * K * c->Mp * c->Mp * 2) AL(c->STh, (size_t)3 * K * c->Mp * c->Mp * 2) }
+  if (c->esz == 4) { AL(c->vbs, (size_t)K * round_up(n_cap, 64) * sizeof(float)) }
   AL(c->phi, (size_t)K * V * c->esz)
   AL(c->Upad, (size_t)GDRF_TILE * c->Mp * c->esz) AL(c->qpart, (size_t)((c->Mp + 63) / 64) * c->ldk * c->esz)
   AL(c->W, (size_t)n_cap * c->Mp * c->esz) AL(c->Wbar, (size_t)n_cap * c->Mp * c->esz)
@@ -1227,6 +1230,24 @@ template <typename T, typename TS> struct Impl {
             const int ntl = tnt_ntiles(Mp), kgroups = (K + TNT_KT - 1) / TNT_KT;
             TNTopicsArgs ta{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbar, ldk, n, rpst, Mp,
                             (float*)c->slab, K, nst, ntl, (const float*)c->ssc, SL.w(), SL.v(0)};
+            static const bool w1 = !(getenv("GDRF_TNT_W1") && getenv("GDRF_TNT_W1")[0] == '0');   // one-wave-per-SIMD form (gemm_tn_topics1.h); 0: the two-wave form
+            if (w1) {
+              int ns1 = c->nsplit_cap < 64 ? c->nsplit_cap : 64;                            // 8 k splits: every XCD owns whole splits
+              if (const char* e = getenv("GDRF_TNT_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= c->nsplit_cap) ns1 = v; }
+              while (ns1 > 8 && (n + ns1 - 1) / ns1 < 8 * TN1_CH) ns1 -= 8;                 // at least 8 chunks per split
+              if (ns1 >= 8) ns1 &= ~7;
+              const int64_t rps1 = round_up((n + ns1 - 1) / ns1, TN1_CH);
+              const int ntl1 = tn1_ntiles(Mp);
+              const int64_t lds64 = round_up(c->ncap, 64);
+              hipLaunchKernelGGL(tn1_scale_rows_kernel, dim3(256, K), dim3(256), 0, s, (const float*)c->vbar, ldk, n, (float*)c->vbs, lds64,
+                                 (const float*)c->ssc, SL.v(0));
+              TNTopicsArgs t1{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbs, lds64, n, rps1, Mp,
+                              (float*)c->slab, K, ns1, ntl1, (const float*)c->ssc, SL.w(), SL.v(0)};
+              HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn1_lds_bytes()));
+              hipLaunchKernelGGL(tn_topics_w1_kernel, dim3((unsigned)(ntl1 * kgroups * ns1)), dim3(256), tn1_lds_bytes(), s, t1);
+              LAUNCHCHK("tn_topics_w1");
+              red_ns = ns1; red_qd = 32;
+            } else {
             static const int pph = getenv("GDRF_TNT_PPH") ? atoi(getenv("GDRF_TNT_PPH")) : 3;     // topic pairs per phase (A/B knob)
 #define GDRF_TNT(X) { HIPCHK(hipFuncSetAttribute((const void*)tn_topics_f16_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, tnt_lds_bytes(X))); \
                       hipLaunchKernelGGL(tn_topics_f16_kernel<X>, dim3((unsigned)(ntl * kgroups * nst)), dim3(512), tnt_lds_bytes(X), s, ta); }
@@ -1234,6 +1255,7 @@ template <typename T, typename TS> struct Impl {
 #undef GDRF_TNT
             LAUNCHCHK("tn_topics");
             red_ns = nst; red_qd = 32;
+            }
           }
         } else if (c->split) {
           const int ib = SplitLay{K}.v(0), ntl = c->nt * (c->nt + 1) / 2;
