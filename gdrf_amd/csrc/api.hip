@@ -1230,21 +1230,45 @@ template <typename T, typename TS> struct Impl {
             const int ntl = tnt_ntiles(Mp), kgroups = (K + TNT_KT - 1) / TNT_KT;
             TNTopicsArgs ta{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbar, ldk, n, rpst, Mp,
                             (float*)c->slab, K, nst, ntl, (const float*)c->ssc, SL.w(), SL.v(0)};
-            static const bool w1 = !(getenv("GDRF_TNT_W1") && getenv("GDRF_TNT_W1")[0] == '0');   // one-wave-per-SIMD form (gemm_tn_topics1.h); 0: the two-wave form
+            static const int w1 = getenv("GDRF_TNT_W1") ? atoi(getenv("GDRF_TNT_W1")) : 2;   // one-wave-per-SIMD forms (gemm_tn_topics1.h): 2 = 128 rows per wave, 1 = 64; 0: the two-wave form
             if (w1) {
               int ns1 = c->nsplit_cap < 64 ? c->nsplit_cap : 64;                            // 8 k splits: every XCD owns whole splits
               if (const char* e = getenv("GDRF_TNT_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= c->nsplit_cap) ns1 = v; }
               while (ns1 > 8 && (n + ns1 - 1) / ns1 < 8 * TN1_CH) ns1 -= 8;                 // at least 8 chunks per split
               if (ns1 >= 8) ns1 &= ~7;
               const int64_t rps1 = round_up((n + ns1 - 1) / ns1, TN1_CH);
-              const int ntl1 = tn1_ntiles(Mp);
+              const int ntl1 = w1 == 2 ? tnt_ntiles(Mp) : tn1_ntiles(Mp);
               const int64_t lds64 = round_up(c->ncap, 64);
               hipLaunchKernelGGL(tn1_scale_rows_kernel, dim3(256, K), dim3(256), 0, s, (const float*)c->vbar, ldk, n, (float*)c->vbs, lds64,
                                  (const float*)c->ssc, SL.v(0));
               TNTopicsArgs t1{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbs, lds64, n, rps1, Mp,
                               (float*)c->slab, K, ns1, ntl1, (const float*)c->ssc, SL.w(), SL.v(0)};
-              HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn1_lds_bytes()));
-              hipLaunchKernelGGL(tn_topics_w1_kernel, dim3((unsigned)(ntl1 * kgroups * ns1)), dim3(256), tn1_lds_bytes(), s, t1);
+              if (w1 == 2) {
+                HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn2_lds_bytes()));
+#ifdef GDRF_TN2_STAMPS   // diagnostic builds only
+                unsigned long long* st_d = nullptr;
+                if (getenv("GDRF_TN2_STAMP_FILE")) {
+                  HIPCHK(hipMalloc((void**)&st_d, 256 * 8 * 8)); HIPCHK(hipMemset(st_d, 0, 256 * 8 * 8));
+                  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tn2_stamps), &st_d, sizeof(st_d)));
+                  HIPCHK(hipDeviceSynchronize());
+                }
+#endif
+                hipLaunchKernelGGL(tn_topics_w2_kernel, dim3((unsigned)(ntl1 * kgroups * ns1)), dim3(256), tn2_lds_bytes(), s, t1);
+#ifdef GDRF_TN2_STAMPS
+                if (st_d) {
+                  HIPCHK(hipDeviceSynchronize());
+                  std::vector<unsigned long long> h(256 * 8);
+                  HIPCHK(hipMemcpy(h.data(), st_d, h.size() * 8, hipMemcpyDeviceToHost));
+                  if (FILE* f = fopen(getenv("GDRF_TN2_STAMP_FILE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                  unsigned long long* z = nullptr;
+                  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tn2_stamps), &z, sizeof(z)));
+                  (void)hipFree(st_d);
+                }
+#endif
+              } else {
+                HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn1_lds_bytes()));
+                hipLaunchKernelGGL(tn_topics_w1_kernel, dim3((unsigned)(ntl1 * kgroups * ns1)), dim3(256), tn1_lds_bytes(), s, t1);
+              }
               LAUNCHCHK("tn_topics_w1");
               red_ns = ns1; red_qd = 32;
             } else {

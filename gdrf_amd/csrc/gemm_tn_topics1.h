@@ -25,9 +25,17 @@
 // Three buffers: the DMA runs two chunks (~5 us) ahead - with one chunk of lookahead the HBM latency under load showed (timing-only
 // ablation without the DMA: 11.4 -> 8.1 ms).
 #pragma once
+#include <utility>
 #include "gemm_tn_topics.h"
 
 namespace gdrf {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}).  (A `#pragma unroll` of 20 stages x 24
+// MFMAs with inline asm in the body is refused by hipcc's unroller - "loop not unrolled" - and the accumulator arrays land in scratch.)
+template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 constexpr int TN1_CH = 64;                        // rows per chunk
 constexpr int TN1_XBLK = 1056;                    // bytes per four-row block of the x image
@@ -43,6 +51,10 @@ constexpr int tn1_lds_bytes() { return TN1_NBUF * TN1_BUF; }
 // 4-byte LDS-DMA (see glds16_asm): lane i's dword lands at lds_dst + 4 i
 __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void glds4_asm_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 // vs[k][n] = vbar[k][n] x block scale of topic k for n < nrows, 0 for nrows <= n < lds (lds a multiple of 64): the row factors as the
@@ -303,6 +315,267 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w1_kernel(TNTopicsArgs g) {
           const int i = i0 + 16 * a + 4 * lg + r;
           const int j = j0 + 16 * w + lr;
           if (i < g.ncols && j < g.ncols) out[(int64_t)i * g.ncols + j] = acc[k][a][r] * un;
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same contraction with 128 rows i per wave: tile 128 (i) x 64 (j), 4 waves x 16 columns.
+//
+// Why: one SIMD has ONE vector issue port, and a 16x16x32 MFMA holds it for 8 of its 16 cycles (MI355X_MICROARCH.md, row 'vector-
+// instruction ISSUE cost') - per MFMA there are 8 cycles of VALU issue to hide in, whether one wave or two share the SIMD.  The split of
+// the row-scaled operand costs the same per B fragment whatever the number of A tiles it is multiplied with, so the VALU cycles per
+// MFMA go with 1 / (rows i per wave): tn_topics_w1_kernel (64 rows, 24 v_fma_mix at 8 cycles per 12 MFMAs) has 16 cycles of split per
+// MFMA and runs VALU-bound (8.85 ms; 5.0 ms with the splits ablated, 5.0 ms with the MFMAs ablated).  Here a B fragment meets 8 A
+// tiles, and the split is rewritten on 4-cycle instructions (v_mul, v_and, v_sub, v_cvt_pk - 10 per element pair instead of 6
+// v_fma_mix at 8): 160 cycles of split + 192 of MFMA issue hold per 384-cycle stage.
+//
+// Accumulators: 8 tiles x 10 topics x 4 = 320 registers per lane.  hipcc puts every MFMA of a 512-register kernel into the AGPR form
+// and then has 256 AGPRs for 320 accumulators (it shuttles them: 1 500 v_accvgpr moves per chunk), so the MFMAs are issued from inline
+// asm with the register file chosen per topic: topics 0 - 7 accumulate in AGPRs, topics 8 and 9 in VGPRs.  Inline asm is outside
+// hipcc's hazard tables; the three cases that matter are covered by construction: an accumulator is touched again 8 MFMAs later (24
+// products of a stage in product-major order), the B fragments of stage t + 1 are written at least 6 MFMAs before stage t + 1 starts,
+// and the epilogue waits two s_nop 15 before it reads the accumulators.
+//
+// The split:  y = x v;  h = y with the mantissa cut to 11 bits (exactly what fp16 holds: v_and, then an exact v_cvt_pkrtz);  l' = 2^11
+// (y - h), the difference exact in f32, rounded to nearest by v_cvt_pk_f16_f32.  |l'| < 2 |h| 2^-10 2^11: same range and the same 22
+// bits as the RNE split of tn_topics_f16_kernel (the cut h is one ulp coarser, the residual carries it).
+constexpr int TN2_A_BYTES = 2 * 2 * 32 * 128 * 2;            // [k-step][piece][32][128] halfwords: 32 KB
+constexpr int TN2_BUF = TN2_A_BYTES + TN1_X_BYTES + TN1_V_BYTES;
+constexpr int TN2_DMA_PER_CHUNK = 15;                          // 8 (A) + 4 (x) + 3 (row factors)
+constexpr int tn2_lds_bytes() { return TN1_NBUF * TN2_BUF; }
+#ifdef GDRF_TN2_STAMPS   // diagnostic builds only: s_memtime stamps of one workgroup's wave 0 (tools/tn2_stamps.py)
+__device__ unsigned long long* g_tn2_stamps = nullptr;       // [chunk][8]
+#define TN2_STAMP(slot) do { if (g_tn2_stamps && blockIdx.x == 1000 && threadIdx.x == 0 && c < 256) g_tn2_stamps[c * 8 + (slot)] = split_stamp(); } while (0)
+#else
+#define TN2_STAMP(slot) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
+  using E = _Float16;
+  using V8 = f16x8;
+  using V4 = f16x4;
+  constexpr int KT = TNT_KT, PIECE = 32 * 128, KA = 8;       // KA: topics whose accumulators live in AGPRs
+  static_assert(KT == 10, "register plan below is for 10 topics");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kgroups = (g.K + KT - 1) / KT;
+  const unsigned units = (unsigned)(g.ntiles * kgroups), bid = blockIdx.x;
+  unsigned u; int sp;
+  if ((g.nsplit & 7) == 0) { const unsigned idx = bid >> 3; sp = (int)(idx / units) * 8 + (int)(bid & 7u); u = idx % units; }
+  else { sp = (int)(bid / units); u = bid % units; }
+  const int tile = (int)(u % (unsigned)g.ntiles), gk = (int)(u / (unsigned)g.ntiles);
+  int I = 0, J = tile;
+  {
+    const int nJ = (g.ncols + 63) / 64;
+    for (;; ++I) { const int cnt = 2 * I + 2 < nJ ? 2 * I + 2 : nJ; if (J < cnt) break; J -= cnt; }
+  }
+  const int i0 = I * 128, j0 = J * 64;
+  const int k0 = gk * KT, kg = min(KT, g.K - k0);
+  const int64_t r0 = (int64_t)sp * g.rows_per_split;
+  int64_t r1 = r0 + g.rows_per_split; if (r1 > g.nrows) r1 = g.nrows;
+  const int nch = r0 < r1 ? (int)((r1 - r0 + TN1_CH - 1) / TN1_CH) : 0;
+  const bool col_ok = (j0 + 16 * w) < g.ncols;
+  const int bj = 2 * J + (w >> 1);                             // 32 x 32 sub-tile column of this wave; its rows: 4 I + a / 2
+
+  f32x4 accA[KA][8], accV[KT - KA][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+#pragma unroll
+    for (int k = 0; k < KA; ++k) accA[k][a] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < KT - KA; ++k) accV[k][a] = f32x4{0, 0, 0, 0};
+  }
+
+  const unsigned lds0 = lds_addr(smem);
+  auto dma_edge = [&](int c, int buf) {                 // chunks that run past the last row: rows clamped per lane
+    const unsigned base = lds0 + (unsigned)(buf * TN2_BUF);
+    const int64_t n0 = r0 + (int64_t)c * TN1_CH;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rb = w + 4 * h, k = 4 * rb + (lane >> 4);
+        const int c8 = (lane & 15) ^ (tnb_code(k) << 1);
+        int64_t n = n0 + 32 * s + k;
+        n = n < g.nrows ? n : g.nrows - 1;
+        const int col = (i0 + 8 * c8 < g.ncols) ? i0 + 8 * c8 : 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          glds16_asm(g.Ah + p * g.a_stride + n * g.lda + col, base + (unsigned)((s * 2 + p) * PIECE * 2 + rb * 1024));
+      }
+    const int xcol = (j0 + 4 * (lane & 15) < g.ncols) ? j0 + 4 * (lane & 15) : 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int blk = 4 * w + t;
+      int64_t n = n0 + 4 * blk + (lane >> 4);
+      n = n < g.nrows ? n : g.nrows - 1;
+      glds16_asm(g.B + n * g.ldb + xcol, base + (unsigned)(TN2_A_BYTES + blk * TN1_XBLK));
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int kk = w + 4 * t, ks = kk < kg ? kk : kg - 1;
+      glds4_asm(g.vbar + (int64_t)(k0 + ks) * g.ldk + n0 + lane, base + (unsigned)(TN2_A_BYTES + TN1_X_BYTES + kk * TN1_CH * 4));
+    }
+  };
+  // chunks inside the rows: wave-uniform 64-bit bases (scalar arithmetic) + one constant 32-bit byte offset per lane and operand kind.
+  // (The per-lane 64-bit address arithmetic and clamps of dma_edge are ~100 vector instructions per chunk, issued with the matrix pipe idle.)
+  unsigned voff_a, voff_x;
+  {
+    const int k = 4 * w + (lane >> 4);
+    const int c8 = (lane & 15) ^ (tnb_code(k) << 1);          // rows k and k + 16 share the swizzle code
+    const int col = (i0 + 8 * c8 < g.ncols) ? i0 + 8 * c8 : 0;
+    voff_a = (unsigned)(((int64_t)(lane >> 4) * g.lda + col) * 2);
+    const int xcol = (j0 + 4 * (lane & 15) < g.ncols) ? j0 + 4 * (lane & 15) : 0;
+    voff_x = (unsigned)(((int64_t)(lane >> 4) * g.ldb + xcol) * 4);
+  }
+  const unsigned voff_v = (unsigned)lane * 4u;
+  auto dma_is_edge = [&](int c) { return r0 + (int64_t)c * TN1_CH + TN1_CH > g.nrows; };
+  // request q = 0 .. 14 of chunk c (not an edge chunk): 8 of A, 4 of x, 3 of the row factors
+  auto dma_piece = [&](int c, int buf, int q) {
+    const int64_t n0 = r0 + (int64_t)c * TN1_CH;
+    const unsigned base = lds0 + (unsigned)(buf * TN2_BUF);
+    if (q < 8) {
+      const int s = q >> 2, h = (q >> 1) & 1, p = q & 1;
+      glds16_asm_s(g.Ah + p * g.a_stride + (n0 + 32 * s + 16 * h + 4 * w) * g.lda, voff_a, base + (unsigned)((s * 2 + p) * PIECE * 2 + (w + 4 * h) * 1024));
+    } else if (q < 12) {
+      const int t = q - 8;
+      glds16_asm_s(g.B + (n0 + 4 * (4 * w + t)) * g.ldb, voff_x, base + (unsigned)(TN2_A_BYTES + (4 * w + t) * TN1_XBLK));
+    } else {
+      const int kk = w + 4 * (q - 12), ks = kk < kg ? kk : kg - 1;
+      glds4_asm_s(g.vbar + (int64_t)(k0 + ks) * g.ldk + n0, voff_v, base + (unsigned)(TN2_A_BYTES + TN1_X_BYTES + kk * TN1_CH * 4));
+    }
+  };
+  auto dma = [&](int c, int buf) {
+    if (dma_is_edge(c)) { dma_edge(c, buf); return; }
+#pragma unroll
+    for (int q = 0; q < TN2_DMA_PER_CHUNK; ++q) dma_piece(c, buf, q);
+  };
+  const int fq = lr >> 2, fp = lr & 3, fcode = ((lg & 1) << 2) | fq;
+  const int fbase = (8 * lg + fq) * 32 + fp;
+  auto frag = [&](const E* img, int g16) -> V8 {
+    const int seg = fbase + ((g16 ^ fcode) << 2);
+    const V4 lo = tr_read(img + seg * 4);
+    const V4 hi = tr_read(img + (seg + 128) * 4);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  // (xa va, xb vb): two consecutive rows of one column -> packed fp16 (h_a, h_b) and (l'_a, l'_b); see the header
+  const unsigned kmask = 0xffffe000u;               // constants in scalar registers: a 32-bit literal makes the instruction two dwords
+  const float k2048 = 2048.0f;
+  // the split in five two-instruction pieces, so that it can be dealt out between single MFMAs: a wave issues in order and the matrix pipe
+  // queues next to nothing - behind six back-to-back MFMAs the ten instructions of a whole split ran with the pipe idle (stamped: 587
+  // cycles per 24-MFMA stage instead of 384)
+  auto split_piece = [&](int q, float xa, float xb, float va, float vb, float& y0, float& y1, float& h0, float& h1, unsigned& H, unsigned& L) {
+    if (q == 0) asm volatile("v_mul_f32 %0, %2, %3\n\tv_mul_f32 %1, %4, %5" : "=&v"(y0), "=&v"(y1) : "v"(xa), "v"(va), "v"(xb), "v"(vb));
+    if (q == 1) asm volatile("v_and_b32 %0, %2, %3\n\tv_and_b32 %1, %2, %4" : "=&v"(h0), "=&v"(h1) : "s"(kmask), "v"(y0), "v"(y1));
+    if (q == 2) asm volatile("v_sub_f32 %0, %0, %2\n\tv_sub_f32 %1, %1, %3" : "+v"(y0), "+v"(y1) : "v"(h0), "v"(h1));
+    if (q == 3) asm volatile("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\tv_mul_f32 %1, %4, %1" : "=&v"(H), "+v"(y0) : "v"(h0), "v"(h1), "s"(k2048));
+    if (q == 4) asm volatile("v_mul_f32 %1, %3, %1\n\tv_cvt_pk_f16_f32 %0, %2, %1" : "=&v"(L), "+v"(y1) : "v"(y0), "s"(k2048));
+  };
+  auto mfma_a = [&](f32x4& acc, const V8& a, const V8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); };
+  auto mfma_v = [&](f32x4& acc, const V8& a, const V8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); };
+  auto wait_next = [&](bool two_ahead) {
+    if (two_ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(TN2_DMA_PER_CHUNK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+
+  if (nch > 0) {
+    dma(0, 0);
+    if (nch > 1) dma(1, 1);
+    wait_next(nch > 1);
+    gdrf_raw_barrier();
+    int buf = 0, bn = 2;
+    for (int c = 0; c < nch; ++c) {
+      const bool two = c + 2 < nch;
+      TN2_STAMP(0);
+      // the DMA of chunk c + 2: one request per stage below, in the stage's last MFMAs (an edge chunk - rows clamped per lane - at once)
+      const bool spread = two && !dma_is_edge(c + 2);
+      if (two && !spread) dma_edge(c + 2, bn);
+      TN2_STAMP(1);
+      const E* As = reinterpret_cast<const E*>(smem + buf * TN2_BUF);
+      const float* xs = reinterpret_cast<const float*>(smem + buf * TN2_BUF + TN2_A_BYTES);
+      const float* vt = reinterpret_cast<const float*>(smem + buf * TN2_BUF + TN2_A_BYTES + TN1_X_BYTES);
+      float xv[2][8];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[s][e] = xs[(8 * s + 2 * lg + (e >> 2)) * (TN1_XBLK / 4) + (e & 3) * 64 + 16 * w + lr];
+      constexpr int NST = 2 * KT;
+      f32x4 vv[3][2];
+      auto load_vv = [&](int t) {
+        const int s = t / KT, k = t % KT;
+        vv[t % 3][0] = *reinterpret_cast<const f32x4*>(vt + k * TN1_CH + 32 * s + 8 * lg);
+        vv[t % 3][1] = *reinterpret_cast<const f32x4*>(vt + k * TN1_CH + 32 * s + 8 * lg + 4);
+      };
+      unsigned Hh[2][4], Ll[2][4];                 // packed B fragments of the stage being multiplied and of the next one
+      float y0, y1, h0, h1;
+      auto piece = [&](int t, int q20) {           // piece q20 = 0 .. 19 of stage t's split: element pair q20 / 5, step q20 % 5
+        const int s = t / KT, g2 = q20 / 5;
+        const f32x4 v = vv[t % 3][g2 >> 1];
+        split_piece(q20 % 5, xv[s][2 * g2], xv[s][2 * g2 + 1], v[2 * (g2 & 1)], v[2 * (g2 & 1) + 1], y0, y1, h0, h1, Hh[t & 1][g2], Ll[t & 1][g2]);
+      };
+      load_vv(0);
+      load_vv(1);
+#pragma unroll
+      for (int q = 0; q < 20; ++q) piece(0, q);
+      V8 fah[8], fal[8], fa2[8];
+      static_for<NST>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int s = t / KT, k = t % KT;
+        if (k == 0) TN2_STAMP(2 + 2 * s);
+        if (k == 1) TN2_STAMP(3 + 2 * s);
+        if (k == 0) {
+#pragma unroll
+          for (int a = 0; a < 8; ++a) { fah[a] = frag(As + (s * 2) * PIECE, a); fal[a] = frag(As + (s * 2 + 1) * PIECE, a); }
+#pragma unroll
+          for (int a = 0; a < 8; ++a) fa2[a] = fah[a] * (E)0.00048828125f;
+        }
+        if (t + 2 < NST) load_vv(t + 2);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const V8 fbh = __builtin_bit_cast(V8, u32x4{Hh[t & 1][0], Hh[t & 1][1], Hh[t & 1][2], Hh[t & 1][3]});
+        const V8 fbl = __builtin_bit_cast(V8, u32x4{Ll[t & 1][0], Ll[t & 1][1], Ll[t & 1][2], Ll[t & 1][3]});
+        // 24 products, product-major: (h_a, l_b) x 8 tiles, (l_a, h_b) x 8, (h_a, h_b) x 8; behind each of the first 20 one piece of the
+        // next stage's split (2 VALU instructions: 8 issue cycles + the MFMA's own 8 = its 16 pipe cycles)
+        static_for<24>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int x = m >> 3, a = m & 7;
+          const V8& fa = x == 0 ? fa2[a] : (x == 1 ? fal[a] : fah[a]);
+          const V8& fb = x == 0 ? fbl : fbh;
+          if (k < KA) mfma_a(accA[k < KA ? k : 0][a], fa, fb); else mfma_v(accV[k >= KA ? k - KA : 0][a], fa, fb);
+          if (m < 20 && t + 1 < NST) piece(t + 1, m);
+          if (m == 21 && spread && t < TN2_DMA_PER_CHUNK) dma_piece(c + 2, bn, t);
+        });
+      });
+      TN2_STAMP(6);
+      wait_next(two);
+      gdrf_raw_barrier();
+      TN2_STAMP(7);
+      buf = buf == 2 ? 0 : buf + 1;
+      bn = bn == 2 ? 0 : bn + 1;
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results (inline asm: outside hipcc's hazard tables)
+  if (!col_ok) return;
+  const float una = g.sc[g.sidx_a + 1];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    if (k < kg) {
+      const float un = una * g.sc[g.sidx_v + 2 * (k0 + k) + 1];
+      float* out = g.slab + ((int64_t)sp * g.K + k0 + k) * (int64_t)g.ncols * g.ncols;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        if (4 * I + (a >> 1) < bj) continue;                   // sub-tile above the diagonal: reduce_slabs_kernel mirrors it from below
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + 16 * a + 4 * lg + r;
+          const int j = j0 + 16 * w + lr;
+          const float v = k < KA ? accA[k < KA ? k : 0][a][r] : accV[k >= KA ? k - KA : 0][a][r];
+          if (i < g.ncols && j < g.ncols) out[(int64_t)i * g.ncols + j] = v * un;
         }
       }
     }

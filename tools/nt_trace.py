@@ -16,7 +16,7 @@ OUT = "gpurun_out/nt_trace.bin"
 os.makedirs("gpurun_out", exist_ok=True)
 
 
-def main():
+def build_step():
     from gdrf_amd.data import synth_circles
     from gdrf_amd.infer import SVI, Trace_ELBO
     from gdrf_amd.kernels import RBF
@@ -35,10 +35,20 @@ def main():
     svi = SVI(model=scale(model.model), guide=scale(model.guide), optim=Adam({"lr": 1e-3}), loss=Trace_ELBO(max_plate_nesting=1, vectorize_particles=True, num_particles=1))
     eng = model._engine_for(N)
 
+    def step():
+        return svi.step(xs=xs, ws=ws, subsample=False)
+    step.eng = eng
+    return step
+
+
+def main():
+    step = build_step()
+    eng = step.eng
+
     class _S:
-        def step(self_):
-            return svi.step(xs=xs, ws=ws, subsample=False)
+        pass
     model = _S()
+    model.step = step
     for _ in range(2):
         model.step()
     torch.cuda.synchronize()
