@@ -6,6 +6,7 @@
 #include "gemm_split.h"
 #include "gemm_tn_topics.h"
 #include "gemm_tn_topics1.h"
+#include "gemm_fwd_t1.h"
 #include "kernels_mm.h"
 #include "kernels_n.h"
 #include "predict.h"
@@ -705,6 +706,11 @@ template <typename T, typename TS> struct Impl {
       if (alt && alt[0] == '1') {
         HIPCHK(hipFuncSetAttribute((const void*)fwd_t_split_2g_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
         hipLaunchKernelGGL(fwd_t_split_2g_kernel<SP>, dim3((unsigned)(8 * K * rt8)), dim3(512), lds2, s, a);
+      } else if (std::is_same<SP, SplitF16>::value && (Mp % 256) == 0 && getenv("GDRF_FWDT_W1") && getenv("GDRF_FWDT_W1")[0] == '1') {     // opt-in: measured slower than the 16-wave form (gemm_fwd_t1.h)
+        if constexpr (std::is_same<SP, SplitF16>::value) {       // one wave per SIMD, 64 rows x 256 columns per wave (gemm_fwd_t1.h)
+          HIPCHK(hipFuncSetAttribute((const void*)fwd_t_w1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ft1_lds_bytes()));
+          hipLaunchKernelGGL(fwd_t_w1_kernel, dim3((unsigned)(8 * K * rt8)), dim3(256), ft1_lds_bytes(), s, a);
+        }
       } else if (SP::NP == 2 && !(getenv("GDRF_FWDT_Q4") && getenv("GDRF_FWDT_Q4")[0] == '0')) {
         if constexpr (SP::NP == 2) {       // 256 x 256 workgroup tiles (two-piece modes: eight operand images in 128 KB)
           constexpr int lds4 = 8 * SplitCfg<SP>::IMG * 2 + 8 * GDRF_TILE * 4;      // + the row-sum slots
@@ -810,7 +816,7 @@ template <typename T, typename TS> struct Impl {
                       hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel<X>, dim3((unsigned)round_up(pairs * nct_, 8), (unsigned)nslice), dim3(512), lds64, s, a); }
 #ifdef GDRF_DIAG
             if (abl == 1) GDRF_K64(1) else if (abl == 2) GDRF_K64(2) else if (abl == 3) GDRF_K64(3) else if (abl == 4) GDRF_K64(4)
-            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else
+            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else if (abl == 16) GDRF_K64(16) else if (abl == 64) GDRF_K64(64) else
 #endif
             GDRF_K64(0)
 #undef GDRF_K64

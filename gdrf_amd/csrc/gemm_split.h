@@ -829,6 +829,25 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
             fbq[(b + 1) & 1][ks][p] = *reinterpret_cast<const V8*>(Bb + (ks * NP + p) * CF::PIECE + (wc * 64 + (b + 1) * 16) * 32 + frag);
       }
       f32x4 P[4];
+      if (ABL & 16) {
+        // timing-only: the same matrix-pipe cycles from HALF as many instructions (32x32x16 instead of two 16x16x32; operands and results
+        // are garbage) - does the kernel wait for the pipe or for the issue slots the MFMAs hold?
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          f32x16 P2;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < SP::NPROD; ++t)
+              P2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][2 * a2][SP::pa(t)], fb[ks][SP::pb(t)],
+                                                          (ks == 0 && t == 0) ? f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : P2, 0, 0, 0);
+#pragma unroll
+          for (int a = 2 * a2; a < 2 * a2 + 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] += s4[a][r] * P2[(a & 1) * 8 + r] + 1e-30f * P2[(a & 1) * 8 + 4 + r];
+        }
+      } else
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -838,25 +857,31 @@ __global__ __launch_bounds__(512, 2) void bwd_wbar_f16_k64_kernel(BwdWbarSplitAr
             if (ABL & 1) acc[a][b] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], acc[a][b]);
             else P[a] = SP::mma(fa[ks][a][SP::pa(t)], fb[ks][SP::pb(t)], (ks == 0 && t == 0) ? f32x4{0, 0, 0, 0} : P[a]);
           }
-      // the next chunk's requests, one or two behind each column group's MFMAs (an LDS-DMA instruction stalls its wave at issue)
-      if (ABL & 8) {
-        // staggered requests: the two waves of a SIMD belong to different groups; group 0 issues all its requests behind b = 0, 1 and
-        // group 1 behind b = 2, 3, so that one wave's issue stalls run under the other's MFMAs instead of both stalling together
-        const int bb = gp ? b - 2 : b;
-        if (bb >= 0 && bb < 2) {
+      // the next chunk's requests behind the first two column groups' MFMAs, so that they have the second half of the phase to land: an
+      // LDS-DMA instruction stalls its wave at issue, but spread over all four groups (one or two each) the last request was issued just
+      // in front of the phase's closing vmcnt(0) and its whole latency showed - 13.3 -> 12.1 ms.  (ABL & 8, timing A/B: the two wave
+      // groups staggered - group 0 behind b = 0, 1, group 1 behind b = 2, 3: 13.7 ms; ABL & 64: everything behind b = 0.)
+      {
+        const int bb = (ABL & 8) ? (gp ? b - 2 : b) : b;
+        if (ABL & 64) {
+          if (b == 0 && !(ABL & 2)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              if (more) { dma_b1(c + 1, ks, 0); dma_b1(c + 1, ks, 1); }
+              if (more_a) { dma_a1(q + 1, ks, 0, 0); dma_a1(q + 1, ks, 1, 0); dma_a1(q + 1, ks, 0, 1); dma_a1(q + 1, ks, 1, 1); }
+            }
+          }
+        } else if (bb >= 0 && bb < 2 && !(ABL & 2)) {
           if (more) { dma_b1(c + 1, bb, 0); dma_b1(c + 1, bb, 1); }
           if (more_a) { dma_a1(q + 1, bb, 0, 0); dma_a1(q + 1, bb, 1, 0); dma_a1(q + 1, bb, 0, 1); dma_a1(q + 1, bb, 1, 1); }
         }
-      } else {
-        if (more && !(ABL & 2)) dma_b1(c + 1, b >> 1, b & 1);
-        if (more_a && !(ABL & 2)) { dma_a1(q + 1, b >> 1, 0, b & 1); dma_a1(q + 1, b >> 1, 1, b & 1); }
       }
-      if (!(ABL & 1)) {
+      if (!(ABL & 1) && !(ABL & 16)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[a][b][r] += s4[a][r] * P[a][r];
-      } else if (b == 3) asm volatile("" :: "v"(s4[0][0] + s4[1][1] + s4[2][2] + s4[3][3]));
+      } else if (b == 3 && (ABL & 1)) asm volatile("" :: "v"(s4[0][0] + s4[1][1] + s4[2][2] + s4[3][3]));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
