@@ -267,7 +267,7 @@ def main():
         # whole 128-wide tiles are computed: executed / useful MFMA work of the triangular and symmetric products
         tile_factor = {"fwd_t": 1.25, "tn_sym": 1.25, "fwd_w": 1.25, "bwd_knm": 1.25}
         if eng.mfma_mode == "f16x3":
-            tile_factor["tn_sym"] = 1.0625       # tn_topics_f16_kernel skips 32 x 32 sub-tiles above the diagonal: 136 of 256 computed for 128 needed
+            tile_factor["tn_sym"] = 1.25         # tn_topics_w2_kernel multiplies whole 128 x 64 tiles (20 of them at M = 512: 160 of 256 blocks for 128 needed)
             tile_factor["fwd_t"] = 1.125         # fwd_t_split_q4_kernel: the triangle at 64-column granularity per wave
         dom = max(flops, key=lambda k: per_step[k])
         dom_t = ms[dom] * 1e-3
@@ -284,7 +284,7 @@ def main():
         f16 = eng.mfma_mode == "f16x3"
         kname = {"fwd_t": "fwd_t_split_q4_kernel" if f16 else "fwd_t_split_cc_kernel",
                  "bwd_wbar": "bwd_wbar_f16_k64_kernel" if f16 else "bwd_wbar_split_kernel",
-                 "tn_sym": "tn_topics_f16_kernel" if f16 else "gemm_tn_split_kernel<A_k>",
+                 "tn_sym": "tn_topics_w2_kernel" if f16 else "gemm_tn_split_kernel<A_k>",
                  "tn_gt": "gemm_tn_split_kernel<GT>"}[dom] if split else (
             f"gemm_nt<{dom}>" if not dom.startswith("tn") else f"gemm_tn<{dom}>")
         # HBM bytes per launch of the dominant kernel from the PMC passes of this command (tools/profile_round.sh -> pmc_hbm.json)

@@ -20,7 +20,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 # timing slot -> substrings of the kernel names that can fill it (the first kernel found wins; one of them runs per configuration)
-SLOT = {"bwd_wbar": ("bwd_wbar_f16_k64_kernel", "bwd_wbar_split"), "fwd_t": ("fwd_t_split",), "tn_sym": ("tn_topics_f16_kernel",),
+SLOT = {"bwd_wbar": ("bwd_wbar_f16_k64_kernel", "bwd_wbar_split"), "fwd_t": ("fwd_t_split",), "tn_sym": ("tn_topics_w2_kernel", "tn_topics_w1_kernel", "tn_topics_f16_kernel"),
         "tn_gt": ("gemm_tn_split_kernel",), "fwd_w": ("FwdWProb",), "bwd_knm": ("BwdKnmProb",),
         "k_nm": ("knm_rbf_f64_kernel", "knm_kernel<double"), "k_nm_f32": ("knm_kernel<float",), "elbo_rows": ("elbo_rows_mfma_kernel", "elbo_rows_kernel"),
         "loc": ("loc_rows_kernel",), "predict": ("predict_mfma_kernel",)}
