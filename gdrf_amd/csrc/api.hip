@@ -1250,27 +1250,14 @@ template <typename T, typename TS> struct Impl {
               TNTopicsArgs t1{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbs, lds64, n, rps1, Mp,
                               (float*)c->slab, K, ns1, ntl1, (const float*)c->ssc, SL.w(), SL.v(0)};
               if (w1 == 2) {
-                HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn2_lds_bytes()));
-#ifdef GDRF_TN2_STAMPS   // diagnostic builds only
-                unsigned long long* st_d = nullptr;
-                if (getenv("GDRF_TN2_STAMP_FILE")) {
-                  HIPCHK(hipMalloc((void**)&st_d, 256 * 8 * 8)); HIPCHK(hipMemset(st_d, 0, 256 * 8 * 8));
-                  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tn2_stamps), &st_d, sizeof(st_d)));
-                  HIPCHK(hipDeviceSynchronize());
-                }
-#endif
-                hipLaunchKernelGGL(tn_topics_w2_kernel, dim3((unsigned)(ntl1 * kgroups * ns1)), dim3(256), tn2_lds_bytes(), s, t1);
-#ifdef GDRF_TN2_STAMPS
-                if (st_d) {
-                  HIPCHK(hipDeviceSynchronize());
-                  std::vector<unsigned long long> h(256 * 8);
-                  HIPCHK(hipMemcpy(h.data(), st_d, h.size() * 8, hipMemcpyDeviceToHost));
-                  if (FILE* f = fopen(getenv("GDRF_TN2_STAMP_FILE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-                  unsigned long long* z = nullptr;
-                  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tn2_stamps), &z, sizeof(z)));
-                  (void)hipFree(st_d);
-                }
-#endif
+                // two launches: the tiles whose upper 64 rows lie above the diagonal (J = 2 I + 1) multiply half the A tiles (gemm_tn_topics1.h)
+                const int nth = tn2_ntiles_half(Mp);
+                TNTopicsArgs t0 = t1, t4 = t1;
+                t0.ntiles = ntl1 - nth; t4.ntiles = nth;
+                HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, tn2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, tn2_lds_bytes()));
+                if (t0.ntiles > 0) hipLaunchKernelGGL(tn_topics_w2_kernel<0>, dim3((unsigned)(t0.ntiles * kgroups * ns1)), dim3(256), tn2_lds_bytes(), s, t0);
+                if (t4.ntiles > 0) hipLaunchKernelGGL(tn_topics_w2_kernel<4>, dim3((unsigned)(t4.ntiles * kgroups * ns1)), dim3(256), tn2_lds_bytes(), s, t4);
               } else {
                 HIPCHK(hipFuncSetAttribute((const void*)tn_topics_w1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tn1_lds_bytes()));
                 hipLaunchKernelGGL(tn_topics_w1_kernel, dim3((unsigned)(ntl1 * kgroups * ns1)), dim3(256), tn1_lds_bytes(), s, t1);

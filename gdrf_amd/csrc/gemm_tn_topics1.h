@@ -354,6 +354,18 @@ __device__ unsigned long long* g_tn2_stamps = nullptr;       // [chunk][8]
 #define TN2_STAMP(slot) do {} while (0)
 #endif
 
+// AMIN: the first A tile (16 rows) the workgroups of this launch multiply.  The tiles J = 2 I + 1 start 64 columns right of their first
+// row, so their rows i0 .. i0 + 63 (A tiles 0 - 3) lie entirely above the diagonal: 12 MFMAs per stage instead of 24 (such a stage is as long
+// as its split - 20 pieces, 160 issue cycles + 96 of MFMA hold - not half as long).  They run as a launch of their own (AMIN = 4: g.ntiles
+// of them, tile t = (I = t, J = 2 t + 1)) behind the launch of all the others (AMIN = 0): a branch around the asm MFMAs would make hipcc
+// copy accumulators, and a lambda instantiated twice inside one kernel left its captures in scratch memory.
+__host__ __device__ inline int tn2_ntiles_half(int ncols) {            // tiles (I, 2 I + 1) inside the matrix
+  const int nI = (ncols + 127) / 128, nJ = (ncols + 63) / 64;
+  int t = 0;
+  for (int I = 0; I < nI; ++I) t += (2 * I + 1 < nJ) ? 1 : 0;
+  return t;
+}
+template <int AMIN>
 __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
   using E = _Float16;
   using V8 = f16x8;
@@ -371,9 +383,11 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
   else { sp = (int)(bid / units); u = bid % units; }
   const int tile = (int)(u % (unsigned)g.ntiles), gk = (int)(u / (unsigned)g.ntiles);
   int I = 0, J = tile;
-  {
+  if (AMIN == 4) { I = tile; J = 2 * tile + 1; }
+  else {
+    // the tiles (I, J), J <= 2 I + 1, J < nJ, without those of the other launch (J == 2 I + 1)
     const int nJ = (g.ncols + 63) / 64;
-    for (;; ++I) { const int cnt = 2 * I + 2 < nJ ? 2 * I + 2 : nJ; if (J < cnt) break; J -= cnt; }
+    for (;; ++I) { const int cnt = 2 * I + 1 < nJ ? 2 * I + 1 : nJ; if (J < cnt) break; J -= cnt; }
   }
   const int i0 = I * 128, j0 = J * 64;
   const int k0 = gk * KT, kg = min(KT, g.K - k0);
@@ -485,6 +499,7 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
   };
 
   if (nch > 0) {
+    constexpr int NA = 8 - AMIN, NM = 3 * NA, NPS = NM - 2;     // NPS: MFMA slots that carry split pieces
     dma(0, 0);
     if (nch > 1) dma(1, 1);
     wait_next(nch > 1);
@@ -523,6 +538,13 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
       load_vv(1);
 #pragma unroll
       for (int q = 0; q < 20; ++q) piece(0, q);
+      // A VGPR written by a VALU instruction must not be read by an MFMA within the next two wait states; hipcc pads that for its own MFMAs,
+      // not for inline asm.  Every operand that compiler-generated VALU code may have touched (the packed fragment tuples, the 2^-11 copies)
+      // therefore passes through an asm statement that pins the point where it exists: `s_nop 1` behind it, or two MFMAs of the stage before.
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      V8 fbh = __builtin_bit_cast(V8, u32x4{Hh[0][0], Hh[0][1], Hh[0][2], Hh[0][3]});
+      V8 fbl = __builtin_bit_cast(V8, u32x4{Ll[0][0], Ll[0][1], Ll[0][2], Ll[0][3]});
+      asm volatile("s_nop 1" : "+v"(fbh), "+v"(fbl));
       V8 fah[8], fal[8], fa2[8];
       static_for<NST>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
@@ -531,24 +553,32 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
         if (k == 1) TN2_STAMP(3 + 2 * s);
         if (k == 0) {
 #pragma unroll
-          for (int a = 0; a < 8; ++a) { fah[a] = frag(As + (s * 2) * PIECE, a); fal[a] = frag(As + (s * 2 + 1) * PIECE, a); }
+          for (int a = AMIN; a < 8; ++a) { fah[a] = frag(As + (s * 2) * PIECE, a); fal[a] = frag(As + (s * 2 + 1) * PIECE, a); }
 #pragma unroll
-          for (int a = 0; a < 8; ++a) fa2[a] = fah[a] * (E)0.00048828125f;
+          for (int a = AMIN; a < 8; ++a) fa2[a] = fah[a] * (E)0.00048828125f;
+          if (AMIN == 0) asm volatile("s_nop 1" : "+v"(fa2[0]), "+v"(fa2[1]), "+v"(fa2[2]), "+v"(fa2[3]), "+v"(fa2[4]), "+v"(fa2[5]), "+v"(fa2[6]), "+v"(fa2[7]));
+          else asm volatile("s_nop 1" : "+v"(fa2[4]), "+v"(fa2[5]), "+v"(fa2[6]), "+v"(fa2[7]));
         }
         if (t + 2 < NST) load_vv(t + 2);
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const V8 fbh = __builtin_bit_cast(V8, u32x4{Hh[t & 1][0], Hh[t & 1][1], Hh[t & 1][2], Hh[t & 1][3]});
-        const V8 fbl = __builtin_bit_cast(V8, u32x4{Ll[t & 1][0], Ll[t & 1][1], Ll[t & 1][2], Ll[t & 1][3]});
-        // 24 products, product-major: (h_a, l_b) x 8 tiles, (l_a, h_b) x 8, (h_a, h_b) x 8; behind each of the first 20 one piece of the
-        // next stage's split (2 VALU instructions: 8 issue cycles + the MFMA's own 8 = its 16 pipe cycles)
-        static_for<24>([&](auto mc) {
+        const V8 fbh_t = fbh, fbl_t = fbl;
+        // NM = 24 (12) products, product-major: (h_a, l_b) x NA tiles, (l_a, h_b) x NA, (h_a, h_b) x NA; the 20 pieces of the next stage's split
+        // behind the first NM - 2 of them (one piece = 2 VALU instructions: 8 issue cycles + the MFMA's own 8 = its 16 pipe cycles)
+        static_for<NM>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          constexpr int x = m >> 3, a = m & 7;
+          constexpr int x = m / NA, a = AMIN + m % NA;
           const V8& fa = x == 0 ? fa2[a] : (x == 1 ? fal[a] : fah[a]);
-          const V8& fb = x == 0 ? fbl : fbh;
+          const V8& fb = x == 0 ? fbl_t : fbh_t;
           if (k < KA) mfma_a(accA[k < KA ? k : 0][a], fa, fb); else mfma_v(accV[k >= KA ? k - KA : 0][a], fa, fb);
-          if (m < 20 && t + 1 < NST) piece(t + 1, m);
-          if (m == 21 && spread && t < TN2_DMA_PER_CHUNK) dma_piece(c + 2, bn, t);
+          if (m < NPS && t + 1 < NST) {
+#pragma unroll
+            for (int q = m * 20 / NPS; q < (m + 1) * 20 / NPS; ++q) piece(t + 1, q);
+          }
+          if (m == NPS - 1 && t + 1 < NST) {          // the next stage's fragment tuples exist from here on: two MFMAs follow
+            fbh = __builtin_bit_cast(V8, u32x4{Hh[(t + 1) & 1][0], Hh[(t + 1) & 1][1], Hh[(t + 1) & 1][2], Hh[(t + 1) & 1][3]});
+            fbl = __builtin_bit_cast(V8, u32x4{Ll[(t + 1) & 1][0], Ll[(t + 1) & 1][1], Ll[(t + 1) & 1][2], Ll[(t + 1) & 1][3]});
+            asm volatile("" : "+v"(fbh), "+v"(fbl));
+          }
+          if (m == NM - 2 && spread && t < TN2_DMA_PER_CHUNK) dma_piece(c + 2, bn, t);
         });
       });
       TN2_STAMP(6);

@@ -57,7 +57,7 @@ def _run(m, eps, **env):
         eng.loss_and_grads(xs, ws, e)
         torch.cuda.synchronize()
         A2 = eng.red_T[lay["A"]:lay["A"] + m.K * Mp * Mp].view(m.K, Mp, Mp)[:, :m.M, :m.M].cpu().double().numpy()
-        assert np.array_equal(A, A2)
+        assert np.array_equal(A, A2), (env, float(np.abs(A - A2).max()), float(np.abs(A).max()))
     return dict(A=np.tril(A), A_ref=np.tril(A_ref), tt=tt, tt_ref=tt_ref, grads=grads)
 
 
