@@ -1236,7 +1236,9 @@ template <typename T, typename TS> struct Impl {
             const int ntl = tnt_ntiles(Mp), kgroups = (K + TNT_KT - 1) / TNT_KT;
             TNTopicsArgs ta{(const _Float16*)c->Wh, (int64_t)c->ncap * Mp, Mp, (const float*)c->W, Mp, (const float*)c->vbar, ldk, n, rpst, Mp,
                             (float*)c->slab, K, nst, ntl, (const float*)c->ssc, SL.w(), SL.v(0)};
-            const int w1 = getenv("GDRF_TNT_W1") ? atoi(getenv("GDRF_TNT_W1")) : 2;   // one-wave-per-SIMD forms (gemm_tn_topics1.h): 2 = 128 rows per wave, 1 = 64; 0: the two-wave form
+            // The one-wave forms run every stage of their 10-topic groups whatever K: with more than 40 % of the topic slots empty (K <= 5, K = 11 .. 12)
+            // the two-wave form, which walks the topic pairs that exist, is the faster one.
+            const int w1 = getenv("GDRF_TNT_W1") ? atoi(getenv("GDRF_TNT_W1")) : (10 * K >= 6 * kgroups * TNT_KT ? 2 : 0);   // one-wave-per-SIMD forms (gemm_tn_topics1.h): 2 = 128 rows per wave, 1 = 64; 0: the two-wave form
             if (w1) {
               int ns1 = c->nsplit_cap < 64 ? c->nsplit_cap : 64;                            // 8 k splits: every XCD owns whole splits
               if (const char* e = getenv("GDRF_TNT_NSPLIT")) { const int v = atoi(e); if (v > 0 && v <= c->nsplit_cap) ns1 = v; }
