@@ -515,6 +515,11 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
       const E* As = reinterpret_cast<const E*>(smem + buf * TN2_BUF);
       const float* xs = reinterpret_cast<const float*>(smem + buf * TN2_BUF + TN2_A_BYTES);
       const float* vt = reinterpret_cast<const float*>(smem + buf * TN2_BUF + TN2_A_BYTES + TN1_X_BYTES);
+      // behind the barrier every LDS read of the chunk's first stage is issued before anything waits for one: the A fragments of k-step 0
+      // first (the pieces of the first split used to run in front of them: their latency showed once per chunk)
+      V8 fah[8], fal[8], fa2[8];
+#pragma unroll
+      for (int a = AMIN; a < 8; ++a) { fah[a] = frag(As, a); fal[a] = frag(As + PIECE, a); }
       float xv[2][8];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -537,6 +542,8 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
       load_vv(0);
       load_vv(1);
 #pragma unroll
+      for (int a = AMIN; a < 8; ++a) fa2[a] = fah[a] * (E)0.00048828125f;
+#pragma unroll
       for (int q = 0; q < 20; ++q) piece(0, q);
       // A VGPR written by a VALU instruction must not be read by an MFMA within the next two wait states; hipcc pads that for its own MFMAs,
       // not for inline asm.  Every operand that compiler-generated VALU code may have touched (the packed fragment tuples, the 2^-11 copies)
@@ -545,17 +552,18 @@ __global__ __launch_bounds__(256, 1) void tn_topics_w2_kernel(TNTopicsArgs g) {
       V8 fbh = __builtin_bit_cast(V8, u32x4{Hh[0][0], Hh[0][1], Hh[0][2], Hh[0][3]});
       V8 fbl = __builtin_bit_cast(V8, u32x4{Ll[0][0], Ll[0][1], Ll[0][2], Ll[0][3]});
       asm volatile("s_nop 1" : "+v"(fbh), "+v"(fbl));
-      V8 fah[8], fal[8], fa2[8];
       static_for<NST>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int s = t / KT, k = t % KT;
         if (k == 0) TN2_STAMP(2 + 2 * s);
         if (k == 1) TN2_STAMP(3 + 2 * s);
         if (k == 0) {
+          if (s == 1) {
 #pragma unroll
-          for (int a = AMIN; a < 8; ++a) { fah[a] = frag(As + (s * 2) * PIECE, a); fal[a] = frag(As + (s * 2 + 1) * PIECE, a); }
+            for (int a = AMIN; a < 8; ++a) { fah[a] = frag(As + 2 * PIECE, a); fal[a] = frag(As + 3 * PIECE, a); }
 #pragma unroll
-          for (int a = AMIN; a < 8; ++a) fa2[a] = fah[a] * (E)0.00048828125f;
+            for (int a = AMIN; a < 8; ++a) fa2[a] = fah[a] * (E)0.00048828125f;
+          }
           if (AMIN == 0) asm volatile("s_nop 1" : "+v"(fa2[0]), "+v"(fa2[1]), "+v"(fa2[2]), "+v"(fa2[3]), "+v"(fa2[4]), "+v"(fa2[5]), "+v"(fa2[6]), "+v"(fa2[7]));
           else asm volatile("s_nop 1" : "+v"(fa2[4]), "+v"(fa2[5]), "+v"(fa2[6]), "+v"(fa2[7]));
         }
