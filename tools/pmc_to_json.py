@@ -47,8 +47,10 @@ def main():
             kw = [(k, v) for k, v in w.items() if pat in k]
             kf = [v for k, v in f.items() if pat in k]
             if kw and kf:
-                out["kernels"][slot] = {"kernel": kw[0][0].split("(")[0][:96], "write_bytes": kw[0][1] * 1024, "fetch_bytes_corrected": 2 * kf[0] * 1024,
-                                        "traffic_bytes": (2 * kf[0] + kw[0][1]) * 1024}
+                # a slot can be several launches per step (A_k: tn_topics_w2_kernel<0> and <4>): their bytes add
+                wsum, fsum = sum(v for _, v in kw), sum(kf)
+                out["kernels"][slot] = {"kernel": " + ".join(sorted(k.split("(")[0][:96] for k, _ in kw)), "write_bytes": wsum * 1024,
+                                        "fetch_bytes_corrected": 2 * fsum * 1024, "traffic_bytes": (2 * fsum + wsum) * 1024}
                 break
     json.dump(out, sys.stdout, indent=1)
 
