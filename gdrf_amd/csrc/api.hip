@@ -816,7 +816,7 @@ template <typename T, typename TS> struct Impl {
                       hipLaunchKernelGGL(bwd_wbar_f16_k64_kernel<X>, dim3((unsigned)round_up(pairs * nct_, 8), (unsigned)nslice), dim3(512), lds64, s, a); }
 #ifdef GDRF_DIAG
             if (abl == 1) GDRF_K64(1) else if (abl == 2) GDRF_K64(2) else if (abl == 3) GDRF_K64(3) else if (abl == 4) GDRF_K64(4)
-            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else if (abl == 16) GDRF_K64(16) else if (abl == 64) GDRF_K64(64) else
+            else if (abl == 7) GDRF_K64(7) else if (abl == 8) GDRF_K64(8) else if (abl == 16) GDRF_K64(16) else if (abl == 64) GDRF_K64(64) else if (abl == 256) GDRF_K64(256) else
 #endif
             GDRF_K64(0)
 #undef GDRF_K64
