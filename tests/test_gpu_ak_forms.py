@@ -2,8 +2,8 @@
 per SIMD with 64 or - the default - 128 rows per wave, inline-asm MFMAs, AGPR accumulators, 3-deep LDS-DMA ring) and the two forms of the
 tt kernel (16 waves / the opt-in one-wave form of csrc/gemm_fwd_t1.h), each against the fp64 product of the engine's OWN float32 inputs, on
 shapes that reach their edges: rows that are no multiple of the 64-row chunk, splits with no rows at all, more topics than one
-accumulator group holds (K = 12 -> groups of 10 + 2), fewer (K = 3), a padded inducing count (M = 100 -> Mp = 128), and the headline's
-M = 512.  The forms are selected per call through the library's environment knobs (GDRF_TNT_W1, GDRF_FWDT_W1)."""
+accumulator group holds (K = 12 -> groups of 10 + 2), fewer (K = 3), a padded inducing count (M = 100 -> Mp = 128), an inducing count that
+is no multiple of the tiles (M = 480), and the headline's M = 512.  The forms are selected per call through the library's environment knobs (GDRF_TNT_W1, GDRF_FWDT_W1)."""
 import os
 
 import numpy as np
@@ -18,6 +18,7 @@ SHAPES = {
     "m256_k10_ragged_rows": dict(kind="rbf", W=41, H=25, V=20, K=10, n_points=(16, 16), lengthscale=0.08),       # N = 1025
     "m100_k12_two_groups": dict(kind="matern52", W=40, H=25, V=12, K=12, n_points=(10, 10), lengthscale=0.12),   # Mp = 128
     "m512_k3": dict(kind="rbf", W=60, H=50, V=20, K=3, n_points=(32, 16), lengthscale=0.1),
+    "m480_k10_partial_tiles": dict(kind="rbf", W=50, H=40, V=20, K=10, n_points=(24, 20), lengthscale=0.1),       # Mp = 480: the last 128 / 64 tiles are partial
 }
 
 
